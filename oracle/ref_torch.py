@@ -1,0 +1,166 @@
+"""TEST INFRASTRUCTURE - CPU oracle #1: PyTorch-eager restatement of the reference's
+EM-Dirichlet / Hard EM-Dirichlet loop.
+
+Not part of the product.  Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline
+leg may import this file; the product path (transductive-clip_amd/) never does and fails
+loudly when its HIP library is missing.
+
+What it is: a functional restatement of the algorithm that issues the SAME torch CPU ops in
+the SAME order as the reference (same broadcast (N,Q,K,K) temporaries, same reductions, fp32),
+so on one machine it reproduces the reference bit for bit - the special functions are torch's
+own (calc_digamma, Sleef lgammaf/logf/expf) and the summation orders are torch's.  That is what
+licenses timing it as "the reference's CPU path" in bench.py (kind "port").
+
+Pinned against: tests/golden/*.npz, produced by running /root/reference itself in the build
+container (tests/golden/make_golden.py); tests/test_oracle_golden.py demands bit-exact
+alpha/u/v/criterions and identical MM iteration counts on every small fixture.
+
+Reference lines followed (paths relative to the reference repo):
+  zero-shot  src/methods/zero_shot/em_dirichlet.py:28-40 (logits), :132-143 (E-step),
+             :145-151 (v), :153-155 (curvature), :157-177 (MM loop), :195-246 (outer loop)
+  hard       src/methods/zero_shot/hard_em_dirichlet.py:255-258
+  few-shot   src/methods/few_shot/em_dirichlet.py:28-39, :167-220;
+             src/methods/few_shot/hard_em_dirichlet.py:228-244
+"""
+import time
+
+import torch
+
+EPS = 1e-15
+MM_CHECK_EVERY = 50
+MM_TOL = 1e-11
+
+
+def one_hot_rows(labels, n_class):
+    """(N,S) int64 -> (N,S,K) f32, as src/utils.py:18-24 builds it (rows of an identity)."""
+    eye = torch.eye(n_class)
+    return torch.stack([eye[row] for row in labels], 0)
+
+
+def mm_solve(alpha, y_cst, iter_mm, pi2_6, lgamma_1):
+    """Majorize-minimize fixed point for the Dirichlet parameters, whole batch at once.
+
+    Returns (alpha_new, number of MM iterations executed).  The stop test couples every task
+    of the batch: squared Frobenius norms over the entire (N,K,K) tensor, every 50 iterations.
+    """
+    beta = alpha.clone()
+    executed = 0
+    for l in range(iter_mm):
+        psi1 = torch.polygamma(0, beta + 1)
+        curv = torch.where(beta > 1e-11,
+                           abs(2 * (lgamma_1 - torch.lgamma(beta + 1) + psi1 * beta) / beta ** 2),
+                           pi2_6)
+        b = psi1 - torch.polygamma(0, beta.sum(-1)).unsqueeze(-1) - curv * beta
+        b = b - y_cst
+        delta = b ** 2 + 4 * curv
+        beta_next = (-b + torch.sqrt(delta)) / (2 * curv)
+        executed += 1
+        if l > 0 and l % MM_CHECK_EVERY == 0:
+            crit = torch.norm(beta_next - beta) ** 2 / torch.norm(beta) ** 2
+            if crit < MM_TOL:
+                break
+        beta = beta_next.clone()
+    return beta_next.clone(), executed
+
+
+def dirichlet_logits(alpha, log_samples):
+    """log Dirichlet density of every sample under every class, (N,n,K)."""
+    l1 = torch.lgamma(alpha.sum(-1)).unsqueeze(1)
+    l2 = -torch.lgamma(alpha).sum(-1).unsqueeze(1)
+    l3 = ((alpha.unsqueeze(1) - 1) * log_samples.unsqueeze(2)).sum(-1)
+    return l1 + l2 + l3
+
+
+def run(x_q, x_s=None, y_s=None, *, n_class, iters, iter_mm=1000, lambd, hard=False, trace=None):
+    """Runs the loop on CPU.  x_q (N,Q,K) probability features; x_s/y_s given = few-shot.
+
+    lambd is the reference's integer `int(K/5)*n_query` (zero-shot) or `int(K/k_eff)*n_query`.
+    Returns dict(u, v, alpha, criterions (iters,), mm_iters list, seconds).
+    `trace`, if a dict, receives per-iteration 'argmax' and 'live' lists.
+    """
+    few = x_s is not None
+    query = x_q.clone().float()
+    n_task, n_query = query.shape[0], query.shape[1]
+    pi2_6 = torch.polygamma(1, torch.Tensor([1])).float()
+    lgamma_1 = torch.lgamma(torch.Tensor([1])).float()
+
+    v = torch.zeros(n_task, n_class)
+    u = query.clone()
+    alpha = torch.ones((n_task, n_class, n_class))
+    alpha_old = alpha.clone()
+    if few:
+        support = x_s.clone().float()
+        ys_hot = one_hot_rows(y_s.long().view(n_task, -1), n_class)
+        support.add_(EPS).log_()
+        query.add_(EPS).log_()          # few-shot works on log-features from here on
+        log_q = query
+    criterions, mm_iters = [], []
+    t0 = time.time()
+    for _ in range(iters):
+        if few:
+            denom = (1 / (ys_hot.sum(dim=1) + u.sum(dim=1))).unsqueeze(-1)
+            y_cst = denom * ((ys_hot.unsqueeze(-1) * support.unsqueeze(2)).sum(dim=1)
+                             + (u.unsqueeze(-1) * log_q.unsqueeze(2)).sum(dim=1))
+            alpha, n_mm = mm_solve(alpha, y_cst, iter_mm, pi2_6, lgamma_1)
+        else:
+            sizes = u.sum(dim=1).unsqueeze(-1).float()
+            live = sizes > EPS
+            y_cst = ((u.unsqueeze(-1) * torch.log(query + EPS).unsqueeze(2)).sum(1)
+                     / u.sum(1).clamp(min=EPS).unsqueeze(-1))
+            y_cst = y_cst * live + (1 - 1 * live) * torch.ones_like(y_cst) * (-10)
+            alpha, n_mm = mm_solve(alpha, y_cst, iter_mm, pi2_6, lgamma_1)
+            alpha = alpha * live + alpha_old * (1 - 1 * live)
+            if trace is not None:
+                trace.setdefault("live", []).append(live.squeeze(-1).clone())
+        mm_iters.append(n_mm)
+        # v uses the responsibilities from BEFORE this iteration's E-step
+        v = torch.log(u.sum(1) / u.size(1) + EPS) + 1
+        logits = dirichlet_logits(alpha, log_q if few else torch.log(query + EPS))
+        u = (logits + lambd * v.unsqueeze(1) / n_query).softmax(2)
+        if hard:
+            labels = torch.argmax(u, dim=-1)
+            u.zero_()
+            u.scatter_(2, labels.unsqueeze(-1), 1.0)
+        if trace is not None:
+            trace.setdefault("argmax", []).append(u.argmax(2).clone())
+        crit = ((alpha_old - alpha).norm(dim=(1, 2)) / alpha_old.norm(dim=(1, 2))).mean(0)
+        alpha_old = alpha.clone()
+        if few and hard:
+            # few_shot/hard_em_dirichlet.py:233-244 evaluates the criterion a second time after
+            # alpha_old was refreshed, so what it logs is identically 0.
+            crit = ((alpha_old - alpha).norm(dim=(1, 2)) / alpha_old.norm(dim=(1, 2))).mean(0)
+        criterions.append(crit)
+    return {"u": u, "v": v, "alpha": alpha, "criterions": torch.stack(criterions),
+            "mm_iters": mm_iters, "seconds": time.time() - t0}
+
+
+def clustering_accuracy(u, x_q, y_q, n_class, graph_matching=True):
+    """Zero-shot accuracy tail (src/methods/zero_shot/em_dirichlet.py:61-92 with
+    src/utils.py:380-417): prototype of each predicted cluster = mean raw feature of its
+    members, clusters (in first-appearance order) assigned to classes by minimum-cost
+    matching on -prototype (scipy Hungarian) or by plain argmax.  Returns (acc (N,1), new_preds)."""
+    import numpy as np
+    from scipy.optimize import linear_sum_assignment
+
+    preds = u.argmax(2)
+    hot = one_hot_rows(preds, n_class)
+    protos = ((hot.unsqueeze(-1) * x_q.unsqueeze(2)).sum(1)) / (hot.sum(1).clamp(min=EPS).unsqueeze(-1))
+    sizes = hot.sum(1).unsqueeze(-1)
+    protos = protos * (sizes > EPS)
+    new_preds = torch.zeros_like(preds)
+    for n in range(preds.shape[0]):
+        if graph_matching:
+            order = []
+            for c in preds[n].tolist():
+                if c not in order:
+                    order.append(c)
+            cost = np.zeros((len(order), n_class))
+            for i, c in enumerate(order):
+                cost[i, :] = -protos[n, c].numpy()
+            _, cls = linear_sum_assignment(cost, maximize=False)
+            lut = {c: int(cls[i]) for i, c in enumerate(order)}
+            new_preds[n] = torch.tensor([lut[c] for c in preds[n].tolist()])
+        else:
+            new_preds[n] = protos[n].argmax(dim=-1)[preds[n]]
+    acc = (new_preds == y_q).float().mean(1, keepdim=True)
+    return acc, new_preds

@@ -1,0 +1,185 @@
+#!/usr/bin/env python3
+"""Generate the golden vectors under tests/golden/ by RUNNING the reference.
+
+Only works in the build container, where /root/reference exists.  The reference's Python
+sources are imported (never copied): `clip` and `torchvision` are absent from this image and
+are not used on the EM-Dirichlet path, so empty stub modules satisfy the import lines
+(SURVEY.md section 8c).  What is committed is data only: seeded inputs and the outputs the
+reference produced for them on torch CPU (fp32), plus per-outer-iteration traces obtained by
+wrapping (not editing) the reference's methods.
+
+    python tests/golden/make_golden.py [case ...]      # default: all small cases
+    python tests/golden/make_golden.py --large         # K=397 / K=1000 cases (minutes)
+"""
+import os
+import sys
+import time
+import types
+
+import numpy as np
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+sys.path.insert(0, os.path.join(ROOT, "transductive-clip_amd"))
+from tclip_amd import synth  # noqa: E402
+
+for _m in ("clip", "torchvision", "torchvision.transforms"):
+    sys.modules.setdefault(_m, types.ModuleType(_m))
+REF = "/root/reference"
+
+
+class Args(dict):
+    __getattr__ = dict.__getitem__
+    __setattr__ = dict.__setitem__
+
+
+def make_args(K, iters, iter_mm=1000, k_eff=5, shots=0):
+    return Args(iter=iters, iter_mm=iter_mm, num_classes_test=K, n_class=K, n_query=75,
+                k_eff=k_eff, T=30, use_softmax_feature=True, graph_matching=True, shots=shots)
+
+
+def load_reference_classes():
+    sys.path.insert(0, REF)
+    from src.methods.zero_shot.em_dirichlet import EM_DIRICHLET as ZS
+    from src.methods.zero_shot.hard_em_dirichlet import HARD_EM_DIRICHLET as ZSH
+    from src.methods.few_shot.em_dirichlet import EM_DIRICHLET as FS
+    from src.methods.few_shot.hard_em_dirichlet import HARD_EM_DIRICHLET as FSH
+    sys.path.pop(0)
+    return {"zs_soft": ZS, "zs_hard": ZSH, "fs_soft": FS, "fs_hard": FSH}
+
+
+# name: (kind, K, N, iters, shots, seed, full_alpha)
+SMALL = {
+    "zs_soft_K10_N4": ("zs_soft", 10, 4, 20, 0, 2020, True),
+    "zs_soft_K37_N6": ("zs_soft", 37, 6, 20, 0, 2021, True),
+    "zs_soft_K100_N4": ("zs_soft", 100, 4, 20, 0, 2022, True),
+    "zs_hard_K10_N4": ("zs_hard", 10, 4, 10, 0, 2020, True),
+    "zs_hard_K37_N6": ("zs_hard", 37, 6, 10, 0, 2021, True),
+    "zs_hard_K100_N4": ("zs_hard", 100, 4, 10, 0, 2022, True),
+    "fs_soft_K10_N4_s4": ("fs_soft", 10, 4, 20, 4, 2020, True),
+    "fs_soft_K37_N3_s2": ("fs_soft", 37, 3, 20, 2, 2021, True),
+    "fs_hard_K10_N4_s4": ("fs_hard", 10, 4, 10, 4, 2020, True),
+    "fs_hard_K37_N3_s3": ("fs_hard", 37, 3, 10, 3, 2021, True),
+}
+LARGE = {
+    "zs_hard_K397_N2": ("zs_hard", 397, 2, 10, 0, 2023, False),
+    "zs_soft_K397_N1": ("zs_soft", 397, 1, 20, 0, 2024, False),
+    "zs_hard_K1000_N1": ("zs_hard", 1000, 1, 10, 0, 2025, False),
+    "zs_soft_K1000_N1": ("zs_soft", 1000, 1, 20, 0, 2026, False),
+}
+
+
+def run_case(name, spec, classes):
+    kind, K, N, iters, shots, seed, full = spec
+    few = kind.startswith("fs")
+    x_q, y_q = synth.make_query_tasks(N, K, seed=seed, k_eff=(5 if few else None))
+    task = {"x_q": x_q.clone(), "y_q": y_q.clone()}
+    if few:
+        x_s, y_s = synth.make_support(N, K, shots, seed=seed)
+        task["x_s"], task["y_s"] = x_s.clone(), y_s.clone()
+    args = make_args(K, iters, shots=shots)
+    m = classes[kind](model=None, device=torch.device("cpu"), log_file=os.path.join("/tmp", "golden.log"),
+                      args=args)
+
+    trace = {"mm_iters": [], "argmax": [], "live": [], "stop_test": []}
+    sqrt_calls = [0]
+    real_sqrt = torch.sqrt
+
+    def counting_sqrt(*a, **k):
+        sqrt_calls[0] += 1
+        return real_sqrt(*a, **k)
+
+    # the MM stop test is the only caller of torch.norm without a `dim`: record both norms so
+    # that tests can tell a borderline `crit < 1e-11` decision from a wrong one
+    real_norm = torch.norm
+    norm_vals = []
+
+    def recording_norm(x, *a, **k):
+        r = real_norm(x, *a, **k)
+        if not a and not k:
+            norm_vals.append(float(r))
+        return r
+
+    real_update_alpha = m.update_alpha
+
+    def traced_update_alpha(alpha_0, y_cst):
+        sqrt_calls[0] = 0
+        del norm_vals[:]
+        trace["live"].append((m.u.sum(1) > m.eps).numpy().copy())
+        real_update_alpha(alpha_0, y_cst)
+        trace["mm_iters"].append(sqrt_calls[0])
+        row = np.full((19, 2), np.nan, np.float64)     # (checkpoint, [||b'-b||, ||b||]) as fp32 values
+        nv = np.asarray(norm_vals, np.float64).reshape(-1, 2)
+        row[:len(nv)] = nv
+        trace["stop_test"].append(row)
+
+    real_u_update = m.u_update
+
+    def traced_u_update(q):
+        real_u_update(q)
+        trace["argmax"].append(m.u.argmax(2).to(torch.int16).numpy().copy())
+
+    m.update_alpha = traced_update_alpha
+    m.u_update = traced_u_update
+    torch.sqrt = counting_sqrt
+    torch.norm = recording_norm
+    t0 = time.time()
+    try:
+        logs = m.run_task(task_dic=task, shot=shots) if few else m.run_task(task_dic=task)
+    finally:
+        torch.sqrt = real_sqrt
+        torch.norm = real_norm
+    dt = time.time() - t0
+
+    alpha = m.alpha.numpy()
+    out = {
+        "kind": kind, "K": K, "N": N, "iters": iters, "iter_mm": 1000, "shots": shots, "seed": seed,
+        "x_q": x_q.numpy(), "y_q": y_q.numpy(),
+        "mm_iters": np.asarray(trace["mm_iters"], np.int32),
+        "argmax": np.stack(trace["argmax"]),            # (iters, N, Q) int16
+        "live": np.stack(trace["live"]),                # (iters, N, K) bool
+        "stop_test": np.stack(trace["stop_test"]),      # (iters, 19, 2) norms seen by the MM stop test
+        "criterions": np.asarray(logs["criterions"], np.float32),
+        "acc": np.asarray(logs["acc"], np.float32),
+        "v": m.v.numpy(),
+        "torch_version": torch.__version__, "ref_seconds": dt,
+    }
+    if few:
+        out["x_s"], out["y_s"] = x_s.numpy(), y_s.numpy()
+    if full:
+        out["alpha"] = alpha
+        out["u"] = m.u.numpy()
+    else:
+        # K>=397: full alpha is 0.6-4 MB per task; keep the responsibilities, 64 sampled rows
+        # per task and float64 per-row checksums (sum and sum of squares) of every row.
+        rng = np.random.default_rng(seed)
+        rows = np.stack([np.sort(rng.choice(K, size=min(64, K), replace=False)) for _ in range(N)])
+        out["u"] = m.u.numpy()
+        out["alpha_rows_idx"] = rows.astype(np.int32)
+        out["alpha_rows"] = np.stack([alpha[n, rows[n]] for n in range(N)])
+        a64 = alpha.astype(np.float64)
+        out["alpha_rowsum"] = a64.sum(-1)
+        out["alpha_rowsumsq"] = (a64 * a64).sum(-1)
+    path = os.path.join(HERE, name + ".npz")
+    np.savez_compressed(path, **out)
+    print(f"{name}: {dt:.1f}s mm_iters={out['mm_iters'].tolist()} acc={out['acc'].ravel().round(3).tolist()} "
+          f"-> {os.path.getsize(path) / 1e3:.0f} kB", flush=True)
+
+
+def main():
+    argv = sys.argv[1:]
+    table = dict(SMALL)
+    if "--large" in argv:
+        argv.remove("--large")
+        table = dict(LARGE)
+    names = argv or list(table)
+    classes = load_reference_classes()
+    torch.set_num_threads(min(8, os.cpu_count() or 1))
+    allc = {**SMALL, **LARGE}
+    for n in names:
+        run_case(n, allc[n], classes)
+
+
+if __name__ == "__main__":
+    main()
