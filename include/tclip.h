@@ -1,0 +1,104 @@
+/* tclip.h - C ABI of the MI355X (gfx950) EM-Dirichlet / Hard EM-Dirichlet engine.
+ *
+ * The reference (SegoleneMartin/transductive-CLIP) has no native layer: its hot path is a chain
+ * of PyTorch-eager ops inside four Python method classes.  This header is therefore the FFI a
+ * maintainer of the reference would bind (ctypes stub in INTEGRATION.md) to replace, per batch,
+ *     src/methods/zero_shot/em_dirichlet.py:179-246        EM_DIRICHLET.run_method
+ *     src/methods/zero_shot/hard_em_dirichlet.py:200-271   HARD_EM_DIRICHLET.run_method
+ *     src/methods/few_shot/em_dirichlet.py:149-220         EM_DIRICHLET.run_method
+ *     src/methods/few_shot/hard_em_dirichlet.py:172-251    HARD_EM_DIRICHLET.run_method
+ * and the accuracy tail src/methods/zero_shot/em_dirichlet.py:61-92 + src/utils.py:380-417.
+ *
+ * Conventions: every pointer marked "device" is a HIP device pointer of a row-major contiguous
+ * array; the library never allocates device memory (the caller passes a workspace sized by
+ * tclip_workspace_bytes, so PyTorch's caching allocator stays the owner), never synchronises
+ * the stream, and keeps no state between calls except a thread-local error string.  All entry
+ * points return 0 on success and a non-zero code otherwise (see tclip_last_error()).
+ */
+#ifndef TCLIP_H
+#define TCLIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define TCLIP_ABI_VERSION 1
+
+enum {
+    TCLIP_OK = 0,
+    TCLIP_ERR_ARG = 1,        /* bad argument (null pointer, non-positive size, K out of range) */
+    TCLIP_ERR_WORKSPACE = 2,  /* workspace too small or misaligned */
+    TCLIP_ERR_HIP = 3         /* a HIP call failed; text in tclip_last_error() */
+};
+
+/* One call = n_batches independent reference batches of tasks_per_batch tasks each.  Tasks of
+ * one batch are coupled by the majorize-minimize stop test, which the reference evaluates over
+ * the whole (n_task, K, K) tensor every 50 inner iterations (em_dirichlet.py:169-175); batches
+ * never interact.  Task t = b * tasks_per_batch + n. */
+typedef struct tclip_problem {
+    int32_t n_batches;        /* B >= 1                                                        */
+    int32_t tasks_per_batch;  /* N >= 1   (the reference's batch_size)                         */
+    int32_t n_query;          /* Q >= 1   (75 in every reference config)                       */
+    int32_t n_class;          /* K, 2..1024: classes == feature dimension (softmax features)   */
+    int32_t n_support;        /* S >= 0: support rows per task; 0 selects the zero-shot variant */
+    int32_t iters;            /* outer iterations (args.iter: 20 soft / 10 hard)               */
+    int32_t iter_mm;          /* inner MM iteration cap (args.iter_mm: 1000)                   */
+    int32_t lambd;            /* the reference's integer lambd = int(K/5)*Q or int(K/k_eff)*Q  */
+    int32_t hard;             /* 0 = EM_DIRICHLET, 1 = HARD_EM_DIRICHLET                       */
+} tclip_problem;
+
+int tclip_abi_version(void);
+const char* tclip_last_error(void);
+
+/* Bytes of device workspace tclip_em_dirichlet_run needs for this problem (0 on bad input). */
+size_t tclip_workspace_bytes(const tclip_problem* p);
+
+/* Runs the whole loop (A3-A12 of SURVEY.md section 8a) on `stream` and returns without waiting.
+ *   x_q   device [B*N, Q, K] f32  probability features of the query set (rows on the simplex)
+ *   x_s   device [B*N, S, K] f32  support features, NULL iff S == 0
+ *   y_s   device [B*N, S]   i64   support labels in [0, K), NULL iff S == 0
+ *   u     device [B*N, Q, K] f32  out: responsibilities after the last E-step (one-hot if hard)
+ *   v     device [B*N, K]    f32  out: dual variable / log class proportions
+ *   alpha device [B*N, K, K] f32  out: Dirichlet parameters, one K-vector per class
+ *   preds device [B*N, Q]    i32  out: argmax_k u (first maximum, as torch.argmax)
+ *   criterions device [B, iters] f32 out: per outer iteration, mean_n ||a_old-a||_F/||a_old||_F
+ *   mm_iters   device [B, iters] i32 out: MM iterations executed in each outer iteration
+ * Inputs are not modified (the few-shot reference logs x_s/x_q in place; this does not). */
+int tclip_em_dirichlet_run(const tclip_problem* p, const float* x_q, const float* x_s, const int64_t* y_s,
+                           float* u, float* v, float* alpha, int32_t* preds, float* criterions,
+                           int32_t* mm_iters, void* workspace, size_t workspace_bytes, void* stream);
+
+/* Accuracy tail, device half: per task the clusters present in `preds` in first-appearance order
+ * and the mean raw feature of each (compute_acc_clustering, em_dirichlet.py:61-71).
+ *   x_q device [T,Q,K] f32, preds device [T,Q] i32
+ *   n_clusters device [T] i32 out; cluster_ids device [T, Cmax] i32 out (first-appearance order,
+ *   -1 padded); prototypes device [T, Cmax, K] f32 out, with Cmax = min(Q, K)
+ *   workspace: tclip_prototype_workspace_bytes(T, Q, K) device bytes */
+size_t tclip_prototype_workspace_bytes(int32_t n_task, int32_t n_query, int32_t n_class);
+int tclip_cluster_prototypes(int32_t n_task, int32_t n_query, int32_t n_class, const float* x_q,
+                             const int32_t* preds, int32_t* n_clusters, int32_t* cluster_ids,
+                             float* prototypes, void* workspace, size_t workspace_bytes, void* stream);
+
+/* Accuracy tail, host half (all pointers HOST memory): assigns clusters to classes by a
+ * minimum-cost rectangular assignment on cost = -prototype (float64, as utils.py:380-405 feeds
+ * scipy.optimize.linear_sum_assignment) when graph_matching != 0, else by argmax of the
+ * prototype (utils.py:408-417), relabels preds and scores them against y_q.
+ *   new_preds host [T,Q] i32 out, acc host [T] f32 out (mean_q new_pred == y_q) */
+int tclip_match_clusters_host(int32_t n_task, int32_t n_query, int32_t n_class, const int32_t* preds,
+                              const int32_t* n_clusters, const int32_t* cluster_ids,
+                              const float* prototypes, const int64_t* y_q, int32_t graph_matching,
+                              int32_t* new_preds, float* acc);
+
+/* Task construction for the task-batch loop (eval_zero_shot.py:160-168): gathers rows of a
+ * device-resident feature table.  table device [n_rows, K] f32, idx device [n_out] i64,
+ * out device [n_out, K] f32. */
+int tclip_gather_rows(const float* table, int64_t n_rows, int32_t n_class, const int64_t* idx,
+                      int64_t n_out, float* out, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* TCLIP_H */

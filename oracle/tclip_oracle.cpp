@@ -309,3 +309,13 @@ float tclip_oracle_sum_outer(const float* x, long n, long col, long ncols) { ret
 float tclip_oracle_sum_reduce_all(const float* x, long n) { return sum_reduce_all(x, n); }
 
 }  // extern "C"
+
+// softmax over one row as torch's CPU kernel does it (vec_softmax_lastdim: max, Sleef expf of
+// the shifted row, reduce_all sum, one reciprocal, multiply); exposed for the unit tests.
+extern "C" void tclip_oracle_softmax_row(const float* x, float* out, long n) {
+    float mx = x[0];
+    for (long i = 1; i < n; i++) mx = x[i] > mx ? x[i] : mx;
+    for (long i = 0; i < n; i++) out[i] = tclip::exp_f32_sleef(x[i] - mx);
+    const float inv = 1.0f / sum_reduce_all(out, n);
+    for (long i = 0; i < n; i++) out[i] *= inv;
+}

@@ -1,0 +1,108 @@
+"""GPU: the HIP engine (through the C ABI) against the golden vectors produced by the reference.
+
+Tolerances (north star: argmax bit-exact; alpha / responsibilities within 1e-5 relative, fp32):
+  * final argmax of u and the accuracies: exact;
+  * MM iteration counts: exact, except where the reference's own stop test sat within 2 % of its
+    1e-11 threshold (recorded in the fixture's `stop_test`): such a decision is not reproducible
+    by anything but a bit-identical trajectory, and either neighbour count is accepted;
+  * alpha: per task ||a - a_ref||_F / ||a_ref||_F <= 1e-5 (2e-5 where an MM count differs by a
+    borderline decision);  u: max |du| <= 1e-5;  v: max |dv| <= 1e-5 * max(1, |v|).
+"""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import GOLDEN, golden_names
+
+pytestmark = pytest.mark.gpu
+SMALL = [n for n in golden_names() if "K397" not in n and "K1000" not in n]
+LARGE = [n for n in golden_names() if "K397" in n or "K1000" in n]
+
+
+def _run(g):
+    from tclip_amd import engine
+    kind = str(g["kind"])
+    few = kind.startswith("fs")
+    dev = torch.device("cuda:0")
+    K = int(g["K"])
+    res = engine.run_em_dirichlet(
+        torch.from_numpy(g["x_q"]).to(dev),
+        torch.from_numpy(g["x_s"]).to(dev) if few else None,
+        torch.from_numpy(g["y_s"]).to(dev) if few else None,
+        n_batches=1, iters=int(g["iters"]), iter_mm=int(g["iter_mm"]), lambd=int(K / 5) * 75,
+        hard=kind.endswith("hard"))
+    torch.cuda.synchronize()
+    return res
+
+
+def _borderline_iterations(g):
+    """outer iterations whose stop decision in the reference was within 2 % of the threshold"""
+    if "stop_test" not in g.files:
+        return set()
+    st = g["stop_test"].astype(np.float32)
+    with np.errstate(invalid="ignore", divide="ignore"):
+        crit = (st[:, :, 0] ** 2) / (st[:, :, 1] ** 2)
+    near = np.abs(crit / np.float32(1e-11) - 1.0) < 0.02
+    return set(np.nonzero(near.any(axis=1))[0].tolist())
+
+
+def _fro_rel(a, ref):
+    a = a.reshape(a.shape[0], -1).astype(np.float64)
+    ref = ref.reshape(ref.shape[0], -1).astype(np.float64)
+    return np.sqrt(((a - ref) ** 2).sum(1)) / np.sqrt((ref ** 2).sum(1))
+
+
+@pytest.mark.parametrize("name", SMALL)
+def test_engine_matches_reference_golden(name):
+    from tclip_amd import engine
+    g = np.load(os.path.join(GOLDEN, name + ".npz"))
+    few = str(g["kind"]).startswith("fs")
+    res = _run(g)
+    mm = res.mm_iters.cpu().numpy()[0]
+    ref_mm = g["mm_iters"]
+    border = _borderline_iterations(g)
+    diff_it = set(np.nonzero(mm != ref_mm)[0].tolist())
+    assert diff_it <= border, f"MM iteration counts differ outside borderline decisions: {mm} vs {ref_mm}"
+    for i in diff_it:
+        assert abs(int(mm[i]) - int(ref_mm[i])) == 50
+    preds = res.preds.cpu().numpy()
+    assert np.array_equal(preds, g["argmax"][-1].astype(np.int32)), "final argmax differs"
+    tol = 2e-5 if diff_it else 1e-5
+    fro = _fro_rel(res.alpha.cpu().numpy(), g["alpha"])
+    assert fro.max() <= tol, f"alpha Frobenius-relative error {fro.max():.2e}"
+    du = np.abs(res.u.cpu().numpy() - g["u"]).max()
+    assert du <= 1e-5, f"u max abs error {du:.2e}"
+    dv = np.abs(res.v.cpu().numpy() - g["v"]) / np.maximum(1.0, np.abs(g["v"]))
+    assert dv.max() <= 1e-5
+    crit = res.criterions.cpu().numpy()[0]
+    np.testing.assert_allclose(crit, g["criterions"], rtol=(5e-2 if diff_it else 1e-3), atol=1e-7)
+    y_q = torch.from_numpy(g["y_q"]).squeeze(2)
+    if few:
+        acc = (res.preds.cpu().long() == y_q).float().mean(1, keepdim=True).numpy()
+    else:
+        acc_t, _ = engine.clustering_accuracy(torch.from_numpy(g["x_q"]).cuda(), res.preds, y_q)
+        acc = acc_t.numpy().reshape(-1, 1)
+    assert np.array_equal(acc, g["acc"]), f"accuracy differs: {acc.ravel()} vs {g['acc'].ravel()}"
+
+
+@pytest.mark.parametrize("name", LARGE)
+def test_engine_matches_reference_golden_large(name):
+    from tclip_amd import engine
+    g = np.load(os.path.join(GOLDEN, name + ".npz"))
+    res = _run(g)
+    assert np.array_equal(res.mm_iters.cpu().numpy()[0], g["mm_iters"])
+    assert np.array_equal(res.preds.cpu().numpy(), g["argmax"][-1].astype(np.int32))
+    alpha = res.alpha.cpu().numpy()
+    N = alpha.shape[0]
+    rows = g["alpha_rows_idx"]
+    sampled = np.stack([alpha[n, rows[n]] for n in range(N)])
+    assert _fro_rel(sampled, g["alpha_rows"]).max() <= 1e-5
+    a64 = alpha.astype(np.float64)
+    np.testing.assert_allclose(a64.sum(-1), g["alpha_rowsum"], rtol=2e-5)
+    np.testing.assert_allclose((a64 * a64).sum(-1), g["alpha_rowsumsq"], rtol=4e-5)
+    assert np.abs(res.u.cpu().numpy() - g["u"]).max() <= 1e-5
+    acc_t, _ = engine.clustering_accuracy(torch.from_numpy(g["x_q"]).cuda(), res.preds,
+                                          torch.from_numpy(g["y_q"]).squeeze(2))
+    assert np.array_equal(acc_t.numpy().reshape(-1, 1), g["acc"])

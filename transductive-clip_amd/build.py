@@ -1,0 +1,45 @@
+#!/usr/bin/env python3
+"""Builds the HIP library of the engine in-tree: tclip_amd/libtclip.so (gfx950 code object + C ABI).
+
+hipcc cross-compiles without a GPU.  -ffp-contract=off is part of the numerics contract: the
+kernels reproduce the reference's separately rounded fp32 operations and spell every fused
+multiply-add they want explicitly (csrc/tclip_math.h)."""
+import os
+import subprocess
+import sys
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.join(HERE, "csrc")
+OUT = os.path.join(HERE, "tclip_amd", "libtclip.so")
+SOURCES = ["tclip_kernels.hip", "tclip_host.cpp"]
+HEADERS = ["tclip_math.h", "tclip_device.h", os.path.join("..", "..", "include", "tclip.h")]
+
+
+def hipcc():
+    for c in (os.environ.get("HIPCC"), "/opt/rocm/bin/hipcc", "hipcc"):
+        if c and (os.path.isabs(c) and os.path.exists(c) or not os.path.isabs(c)):
+            return c
+    raise RuntimeError("hipcc not found")
+
+
+def up_to_date():
+    if not os.path.exists(OUT):
+        return False
+    t = os.path.getmtime(OUT)
+    deps = [os.path.join(CSRC, f) for f in SOURCES + HEADERS] + [os.path.abspath(__file__)]
+    return all(os.path.getmtime(d) <= t for d in deps)
+
+
+def build(force=False, verbose=False):
+    if not force and up_to_date():
+        return OUT
+    cmd = [hipcc(), "--offload-arch=gfx950", "-O3", "-ffp-contract=off", "-fPIC", "-shared", "-std=c++17",
+           "-Wall", "-Wno-unused-function", "-o", OUT] + [os.path.join(CSRC, s) for s in SOURCES]
+    if verbose:
+        print(" ".join(cmd), flush=True)
+    subprocess.check_call(cmd, cwd=CSRC)
+    return OUT
+
+
+if __name__ == "__main__":
+    print(build(force="--force" in sys.argv, verbose=True))

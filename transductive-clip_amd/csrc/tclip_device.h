@@ -1,0 +1,176 @@
+// Device-side building blocks shared by the kernels in tclip_kernels.hip: reductions that follow
+// the association order of torch's CPU kernels (the reference's arithmetic), laid out on 32-lane
+// half-wavefront groups.
+//
+// Why the order matters: the reference runs on torch CPU fp32; its sums are
+//   * last-dim sums (alpha.sum(-1), lgamma(alpha).sum(-1), the (alpha-1)*log z contraction):
+//     aten SumKernel.cpp vectorized_inner_sum - 8-float vectors (sum_stub has no AVX-512 variant),
+//     4 interleaved vector accumulators, 16-element cascade blocks, then a serial pass over the
+//     8 lanes;
+//   * sums over the query dimension (u.sum(1), the u^T log z statistics): vectorized_outer_sum -
+//     per output column a 16-element cascade, except the last (#columns mod 32) columns, which go
+//     through the 4-way interleaved row sum;
+//   * softmax denominators: vec::reduce_all on 16-float vectors + 8/4/2/1 butterfly.
+// oracle/tclip_oracle.cpp restates the same orders on the CPU and tests/test_oracle_sums.py pins
+// them bit-for-bit against torch.  Element d of a K-vector lives in register e = d / 32 of lane
+// d % 32, which makes (lane / 8, lane % 8, e) exactly torch's (accumulator, vector lane, step).
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include "tclip_math.h"
+
+namespace tclip {
+
+constexpr int kGroup = 32;          // lanes per row
+constexpr float kEpsF = 1e-15f;
+
+__device__ __forceinline__ float group_shfl(float v, int src_lane) { return __shfl(v, src_lane, kGroup); }
+__device__ __forceinline__ double group_shfl_xor(double v, int m) { return __shfl_xor(v, m, kGroup); }
+
+// x[e] holds element 32e + lane (0 where 32e + lane >= K).  Returns torch's x.sum(-1), the same
+// value in all 32 lanes of the group.
+template <int E>
+__device__ __forceinline__ float group_sum_torch(const float (&x)[E], int K, int lane) {
+    if (K < 8) {  // scalar_inner_sum: 4 interleaved scalar accumulators
+        const int size_ilp = K >> 2;
+        float fin = size_ilp ? group_shfl(x[0], 0) : 0.0f;
+        for (int i = size_ilp * 4; i < K; i++) fin += group_shfl(x[0], i);
+        if (size_ilp) {
+            fin += group_shfl(x[0], 1);
+            fin += group_shfl(x[0], 2);
+            fin += group_shfl(x[0], 3);
+        }
+        return fin;
+    }
+    const int vec_size = K >> 3, size_ilp = vec_size >> 2;
+    const int j = lane & 7;
+    float a0 = 0.0f, a1 = 0.0f, ragged = 0.0f;
+#pragma unroll
+    for (int e = 0; e < E; e++) {
+        if (e == 16 && size_ilp >= 16) { a1 += a0; a0 = 0.0f; }
+        if (e < size_ilp) a0 += x[e];
+        if (e == size_ilp) ragged = x[e];
+    }
+    if (E == 32 && size_ilp >= 32) { a1 += a0; a0 = 0.0f; }
+    const float pm = a0 + a1;                       // per-(accumulator, lane) partial
+    // whole vectors beyond the 4-way interleaved part join accumulator 0 in vector order
+    const int nleft = vec_size - 4 * size_ilp;      // 0..3
+    float p0 = pm;
+    const float l1 = group_shfl(ragged, 8 + j), l2 = group_shfl(ragged, 16 + j);
+    if (nleft >= 1) p0 += ragged;
+    if (nleft >= 2) p0 += l1;
+    if (nleft >= 3) p0 += l2;
+    p0 += group_shfl(pm, 8 + j);
+    p0 += group_shfl(pm, 16 + j);
+    p0 += group_shfl(pm, 24 + j);                   // valid in lanes 0..7
+    // scalar tail (K mod 8 elements) first, then the 8 vector lanes in order
+    const int ntail = K - 8 * vec_size, tail_base = 8 * (vec_size & 3);
+    float fin = 0.0f;
+#pragma unroll
+    for (int t = 0; t < 7; t++) {
+        const float tv = group_shfl(ragged, tail_base + t);
+        if (t < ntail) fin += tv;
+    }
+#pragma unroll
+    for (int t = 0; t < 8; t++) fin += group_shfl(p0, t);
+    return fin;
+}
+
+// fp64 sum over the 32 lanes of a group (fixed butterfly order, same value in every lane).
+__device__ __forceinline__ double group_sum_f64(double v) {
+#pragma unroll
+    for (int m = 16; m >= 1; m >>= 1) v += group_shfl_xor(v, m);
+    return v;
+}
+
+__device__ __forceinline__ int dev_ceil_log2(int n) {
+    int l = 0;
+    while ((1 << l) < n) l++;
+    return l;
+}
+
+// torch's multi_row_sum cascade over n values get(0..n-1).
+template <typename F>
+__device__ __forceinline__ float dsum_cascade(int n, F get) {
+    const int cl = dev_ceil_log2(n) / 4;
+    const int level_power = cl > 4 ? cl : 4;
+    const int step = 1 << level_power, mask = step - 1;
+    float acc0 = 0.0f, acc1 = 0.0f, acc2 = 0.0f, acc3 = 0.0f;
+    int i = 0;
+    for (; i + step <= n;) {
+        for (int jj = 0; jj < step; ++jj, ++i) acc0 += get(i);
+        acc1 += acc0; acc0 = 0.0f;
+        if ((i & (mask << level_power)) == 0) {
+            acc2 += acc1; acc1 = 0.0f;
+            if ((i & (mask << (2 * level_power))) == 0) { acc3 += acc2; acc2 = 0.0f; }
+        }
+    }
+    for (; i < n; ++i) acc0 += get(i);
+    acc0 += acc1;
+    acc0 += acc2;
+    acc0 += acc3;
+    return acc0;
+}
+
+// torch's row_sum: 4 interleaved cascades, leftovers into partial 0.
+template <typename F>
+__device__ __forceinline__ float dsum_ilp4(int n, F get) {
+    const int size_ilp = n >> 2;
+    float p0 = dsum_cascade(size_ilp, [&](int m) { return get(4 * m + 0); });
+    const float p1 = dsum_cascade(size_ilp, [&](int m) { return get(4 * m + 1); });
+    const float p2 = dsum_cascade(size_ilp, [&](int m) { return get(4 * m + 2); });
+    const float p3 = dsum_cascade(size_ilp, [&](int m) { return get(4 * m + 3); });
+    for (int i = size_ilp * 4; i < n; i++) p0 += get(i);
+    p0 += p1;
+    p0 += p2;
+    p0 += p3;
+    return p0;
+}
+
+// torch's sum over a strided dimension for output column `col` of `ncols` contiguous columns.
+template <typename F>
+__device__ __forceinline__ float dsum_outer(int n, long col, long ncols, F get) {
+    return col < (ncols / 32) * 32 ? dsum_cascade(n, get) : dsum_ilp4(n, get);
+}
+
+// torch's contiguous last-dim sum evaluated serially by one thread (small n only).
+template <typename F>
+__device__ float dsum_inner_serial(int n, F get) {
+    if (n < 8) return dsum_ilp4(n, get);
+    const int vec_size = n >> 3, size_ilp = vec_size >> 2;
+    float p0[8];
+    for (int jj = 0; jj < 8; jj++) {
+        float p[4];
+        for (int r = 0; r < 4; r++) p[r] = dsum_cascade(size_ilp, [&](int m) { return get(8 * (4 * m + r) + jj); });
+        for (int vv = size_ilp * 4; vv < vec_size; vv++) p[0] += get(8 * vv + jj);
+        p[0] += p[1];
+        p[0] += p[2];
+        p[0] += p[3];
+        p0[jj] = p[0];
+    }
+    float fin = 0.0f;
+    for (int k = vec_size * 8; k < n; k++) fin += get(k);
+    for (int jj = 0; jj < 8; jj++) fin += p0[jj];
+    return fin;
+}
+
+// One majorize-minimize update of a single Dirichlet parameter (em_dirichlet.py:153-167):
+// the operation order, the roundings (no contraction) and the special functions of torch CPU.
+__device__ __forceinline__ float mm_update(float a, float y, float psi_s) {
+    const float x1 = a + 1.0f;
+    const float psi1 = digamma_f32(x1);
+    const float lg1 = lgamma_f32(x1);
+    float curv;
+    if (a > 1e-11f) {
+        const float t = (0.0f - lg1) + psi1 * a;
+        curv = __builtin_fabsf((2.0f * t) / (a * a));
+    } else {
+        curv = 1.6449340668482264f;  // polygamma(1, 1)
+    }
+    float b = (psi1 - psi_s) - curv * a;
+    b = b - y;
+    const float delta = b * b + 4.0f * curv;
+    return (-b + __builtin_sqrtf(delta)) / (2.0f * curv);
+}
+
+}  // namespace tclip

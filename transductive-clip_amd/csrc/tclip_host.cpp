@@ -1,0 +1,117 @@
+// Host half of the accuracy tail (include/tclip.h: tclip_match_clusters_host).
+//
+// The reference assigns predicted clusters to classes with scipy.optimize.linear_sum_assignment
+// on cost = -prototype (src/utils.py:380-405).  scipy is a third-party dependency of the
+// reference (unpinned there; 1.15.3 in this image); its solver is the shortest-augmenting-path
+// algorithm of D. F. Crouse, "On implementing 2D rectangular assignment algorithms", IEEE TAES
+// 52(4), 2016, restated here with the same scanning order and tie rules (unassigned column
+// preferred among equal reduced costs, remaining-column list filled in reverse), because on
+// probability prototypes exact ties (e.g. all-zero columns) do occur and decide the labels.
+#include <math.h>
+#include <stdint.h>
+#include <string.h>
+
+#include <algorithm>
+#include <vector>
+
+#include "../../include/tclip.h"
+
+namespace {
+
+// rows <= cols.  Returns col_of_row.  cost is row-major rows x cols.
+bool assign_rows(int rows, int cols, const double* cost, std::vector<int>& col_of_row) {
+    std::vector<double> u(rows, 0.0), v(cols, 0.0), dist(cols);
+    std::vector<int> pred(cols, -1), row_of_col(cols, -1), todo(cols);
+    std::vector<char> row_seen(rows), col_seen(cols);
+    col_of_row.assign(rows, -1);
+    for (int cur = 0; cur < rows; cur++) {
+        int n_todo = cols;
+        for (int it = 0; it < cols; it++) todo[it] = cols - it - 1;
+        std::fill(row_seen.begin(), row_seen.end(), 0);
+        std::fill(col_seen.begin(), col_seen.end(), 0);
+        std::fill(dist.begin(), dist.end(), INFINITY);
+        double min_val = 0.0;
+        int i = cur, sink = -1;
+        while (sink < 0) {
+            int pick = -1;
+            double lowest = INFINITY;
+            row_seen[i] = 1;
+            for (int it = 0; it < n_todo; it++) {
+                const int j = todo[it];
+                const double r = min_val + cost[(size_t)i * cols + j] - u[i] - v[j];
+                if (r < dist[j]) {
+                    pred[j] = i;
+                    dist[j] = r;
+                }
+                if (dist[j] < lowest || (dist[j] == lowest && row_of_col[j] == -1)) {
+                    lowest = dist[j];
+                    pick = it;
+                }
+            }
+            min_val = lowest;
+            if (min_val == INFINITY) return false;
+            const int j = todo[pick];
+            if (row_of_col[j] == -1) sink = j;
+            else i = row_of_col[j];
+            col_seen[j] = 1;
+            todo[pick] = todo[--n_todo];
+        }
+        u[cur] += min_val;
+        for (int r = 0; r < rows; r++)
+            if (row_seen[r] && r != cur) u[r] += min_val - dist[col_of_row[r]];
+        for (int j = 0; j < cols; j++)
+            if (col_seen[j]) v[j] -= min_val - dist[j];
+        int j = sink;
+        while (true) {
+            const int r = pred[j];
+            row_of_col[j] = r;
+            std::swap(col_of_row[r], j);
+            if (r == cur) break;
+        }
+    }
+    return true;
+}
+
+}  // namespace
+
+extern "C" int tclip_match_clusters_host(int32_t T, int32_t Q, int32_t K, const int32_t* preds,
+                                         const int32_t* n_clusters, const int32_t* cluster_ids,
+                                         const float* prototypes, const int64_t* y_q, int32_t graph_matching,
+                                         int32_t* new_preds, float* acc) {
+    if (T < 1 || Q < 1 || K < 2 || !preds || !n_clusters || !cluster_ids || !prototypes || !y_q || !new_preds || !acc)
+        return TCLIP_ERR_ARG;
+    const int Cmax = Q < K ? Q : K;
+    std::vector<double> cost;
+    std::vector<int> col_of_row, lut(K);
+    for (int t = 0; t < T; t++) {
+        const int C = n_clusters[t];
+        if (C < 1 || C > Cmax) return TCLIP_ERR_ARG;
+        const int32_t* ids = cluster_ids + (size_t)t * Cmax;
+        const float* pr = prototypes + (size_t)t * Cmax * K;
+        std::fill(lut.begin(), lut.end(), 0);
+        if (graph_matching) {
+            cost.resize((size_t)C * K);
+            for (int c = 0; c < C; c++)
+                for (int d = 0; d < K; d++) cost[(size_t)c * K + d] = -(double)pr[(size_t)c * K + d];
+            if (!assign_rows(C, K, cost.data(), col_of_row)) return TCLIP_ERR_ARG;
+            for (int c = 0; c < C; c++) lut[ids[c]] = col_of_row[c];
+        } else {
+            // compute_basic_matching: class = argmax of the cluster's prototype (first maximum)
+            for (int c = 0; c < C; c++) {
+                int best = 0;
+                for (int d = 1; d < K; d++)
+                    if (pr[(size_t)c * K + d] > pr[(size_t)c * K + best]) best = d;
+                lut[ids[c]] = best;
+            }
+        }
+        int hit = 0;
+        for (int q = 0; q < Q; q++) {
+            const int np = lut[preds[(size_t)t * Q + q]];
+            new_preds[(size_t)t * Q + q] = np;
+            hit += (int64_t)np == y_q[(size_t)t * Q + q];
+        }
+        // torch: (new == y).float().mean(1): sum of 0/1 floats (exact) divided by Q in fp32
+        acc[t] = (float)hit / (float)Q;
+    }
+    return TCLIP_OK;
+}

@@ -1,0 +1,830 @@
+// HIP kernels (gfx950 / MI355X) and C ABI of the EM-Dirichlet engine.  See include/tclip.h for the
+// contract and DESIGN.md for the data layout and the per-kernel rooflines.
+//
+// Stream of one outer iteration (reference: src/methods/zero_shot/em_dirichlet.py:214-244):
+//   k_cluster_sizes   cs = sum_q u, live mask, v                                   (:217-218, :151)
+//   k_mstats          y = u^T log z / cs  (+ support statistics in few-shot)       (:219-222)
+//   k_build_rows      compact the rows that must iterate: live rows + dead rows whose stop-test
+//                     contributions are not cached yet
+//   k_mm_chunk x20    <=50 majorize-minimize iterations per launch, alpha rows register-resident,
+//   k_mm_decide x20   batch-global stop test on device, no host round trip          (:157-177)
+//   k_row_consts      lgamma(sum alpha) - sum lgamma(alpha) for rows that changed  (:35-36)
+//   k_logits          (alpha-1) . log z contraction for rows that changed          (:37-38)
+//   k_softmax         u = softmax_k(logit + lambd*v/Q), argmax, one-hot if hard    (:142-143)
+//   k_criterion(+_mean) per-task relative change of alpha; alpha_old <- alpha      (:236-239)
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <string.h>
+
+#include "../../include/tclip.h"
+#include "tclip_device.h"
+
+namespace tclip {
+
+// ------------------------------------------------------------------------------------------
+// element-wise log of the features: log(x + 1e-15)                      (em_dirichlet.py:38)
+__global__ void k_log_features(const float* __restrict__ x, float* __restrict__ out, size_t n) {
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x)
+        out[i] = log_f32(x[i] + kEpsF);
+}
+
+__global__ void k_fill(float* __restrict__ p, float v, size_t n) {
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) p[i] = v;
+}
+
+__global__ void k_copy(const float* __restrict__ s, float* __restrict__ d, size_t n) {
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) d[i] = s[i];
+}
+
+// ------------------------------------------------------------------------------------------
+// Few-shot support statistics, once per run (few_shot/em_dirichlet.py:196-200 recomputes them
+// every iteration from an (N,S,K,K) temporary although they are constant):
+//   cnt[t,k]   = sum_s 1[y_s = k]
+//   sup[t,k,d] = sum_s 1[y_s = k] * log(x_s[d] + eps)   in torch's outer-sum order over ALL s
+// The zero products only matter through the positions of the cascade dumps, so only the members
+// of class k are visited and the dumps that fall between two members are replayed.
+struct SparseCascade {
+    float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+    int lp, nfull, done = 0;   // done = largest block boundary already applied
+    __device__ SparseCascade(int n) {
+        const int cl = dev_ceil_log2(n) / 4;
+        lp = cl > 4 ? cl : 4;
+        nfull = (n >> lp) << lp;
+    }
+    // apply every dump with boundary position in (done, upto]
+    __device__ void dumps_upto(int upto) {
+        if (upto > nfull) upto = nfull;
+        const int step = 1 << lp;
+        int e1 = ((done >> lp) + 1) << lp;                 // next level-1 boundary
+        if (e1 > upto) return;
+        a1 += a0; a0 = 0.f;
+        const int s2 = step << lp;
+        int e2 = ((e1 + s2 - 1) / s2) * s2;                // first level-2 boundary >= e1
+        if (e2 <= upto) {
+            a2 += a1; a1 = 0.f;
+            const int s3 = s2 << lp;
+            int e3 = ((e2 + s3 - 1) / s3) * s3;
+            if (e3 <= upto) { a3 += a2; a2 = 0.f; }
+        }
+        done = (upto >> lp) << lp;
+    }
+    __device__ void add(int pos, float v) { dumps_upto(pos); a0 += v; }
+    __device__ float finish() {
+        dumps_upto(nfull);
+        float r = a0 + a1;
+        r += a2;
+        r += a3;
+        return r;
+    }
+};
+
+// NOTE on SparseCascade::dumps_upto: between two members several level-1 boundaries may pass; only
+// the first moves data (a0 is zero afterwards), likewise for the higher levels, but a level-2 dump
+// can also happen at a LATER boundary than the first level-1 dump (first multiple of step^2 after
+// it).  Because a1 then holds exactly what the first dump put there, replaying "first level-1
+// boundary, then first level-2 boundary >= it, then first level-3 boundary >= that" is equivalent.
+
+__global__ void k_support_stats(const float* __restrict__ xs, const int64_t* __restrict__ ys, int S, int K,
+                                float* __restrict__ sup, float* __restrict__ cnt) {
+    extern __shared__ int members[];               // indices s with ys == k, ascending
+    __shared__ int n_members;
+    const int t = blockIdx.y, k = blockIdx.x;
+    const int64_t* yt = ys + (size_t)t * S;
+    __shared__ int wave_count[16];
+    if (threadIdx.x == 0) n_members = 0;
+    __syncthreads();
+    const int wave = threadIdx.x >> 6, wl = threadIdx.x & 63, n_waves = (blockDim.x + 63) >> 6;
+    for (int s0 = 0; s0 < S; s0 += blockDim.x) {   // order-preserving compaction of {s : y_s == k}
+        const int s = s0 + threadIdx.x;
+        const bool m = s < S && yt[s] == k;
+        const unsigned long long bal = __ballot(m);
+        if (wl == 0) wave_count[wave] = __popcll(bal);
+        __syncthreads();
+        int off = n_members;
+        for (int w = 0; w < wave; w++) off += wave_count[w];
+        if (m) members[off + __popcll(bal & ((1ull << wl) - 1ull))] = s;
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            int tot = 0;
+            for (int w = 0; w < n_waves; w++) tot += wave_count[w];
+            n_members += tot;
+        }
+        __syncthreads();
+    }
+    const int nm = n_members;
+    const float* xt = xs + (size_t)t * S * K;
+    const long ncols = (long)K * K;
+    for (int d = threadIdx.x; d < K; d += blockDim.x) {
+        const long col = (long)k * K + d;
+        float r;
+        if (col < (ncols / 32) * 32) {
+            SparseCascade c(S);
+            for (int i = 0; i < nm; i++) c.add(members[i], log_f32(xt[(size_t)members[i] * K + d] + kEpsF));
+            r = c.finish();
+        } else {   // 4 interleaved cascades over s/4, leftovers (s >= 4*(S/4)) into partial 0
+            const int size_ilp = S >> 2;
+            SparseCascade c0(size_ilp), c1(size_ilp), c2(size_ilp), c3(size_ilp);
+            float extra = 0.f;
+            bool has_extra = false;
+            float p0 = 0.f;
+            // leftovers are added after partial 0's cascade is complete, in order
+            for (int i = 0; i < nm; i++) {
+                const int s = members[i];
+                const float v = log_f32(xt[(size_t)s * K + d] + kEpsF);
+                if (s >= size_ilp * 4) {
+                    if (!has_extra) { p0 = c0.finish(); has_extra = true; }
+                    p0 += v;
+                    (void)extra;
+                } else {
+                    const int m = s >> 2;
+                    switch (s & 3) {
+                        case 0: c0.add(m, v); break;
+                        case 1: c1.add(m, v); break;
+                        case 2: c2.add(m, v); break;
+                        default: c3.add(m, v); break;
+                    }
+                }
+            }
+            if (!has_extra) p0 = c0.finish();
+            p0 += c1.finish();
+            p0 += c2.finish();
+            p0 += c3.finish();
+            r = p0;
+        }
+        sup[((size_t)t * K + k) * K + d] = r;
+    }
+    if (threadIdx.x == 0) cnt[(size_t)t * K + k] = (float)nm;
+}
+
+// ------------------------------------------------------------------------------------------
+// cs[t,k] = sum_q u[t,q,k] (torch outer-sum order), live mask, v = log(cs/Q + eps) + 1.
+// Also invalidates the dead-row cache of rows that are alive.
+__global__ void k_cluster_sizes(const float* __restrict__ u, int T, int Q, int K, int zero_shot,
+                                float* __restrict__ cs, uint8_t* __restrict__ live, float* __restrict__ v,
+                                int32_t* __restrict__ cache_len) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= (size_t)T * K) return;
+    const int t = i / K, k = i % K;
+    const float* ut = u + (size_t)t * Q * K;
+    const float c = dsum_outer(Q, k, K, [&](int q) { return ut[(size_t)q * K + k]; });
+    cs[i] = c;
+    const bool alive = zero_shot ? (c > kEpsF) : true;
+    live[i] = alive;
+    if (alive && cache_len) cache_len[i] = 0;
+    if (v) v[i] = log_f32(c / (float)Q + kEpsF) + 1.0f;
+}
+
+// y[t,k,d] = sum_q u[t,q,k] * f[t,q,d] / max(cs, eps)                         (zero-shot, live rows)
+//          = (sup[t,k,d] + sum_q u f) * (1 / (cnt[t,k] + cs[t,k]))           (few-shot)
+// The same kernel, with f = raw features and u = one-hot predictions, gives the cluster
+// prototypes of the accuracy tail (em_dirichlet.py:66-67).
+__global__ void k_mstats(const float* __restrict__ u, const float* __restrict__ f, const float* __restrict__ cs,
+                         const uint8_t* __restrict__ live, const float* __restrict__ sup,
+                         const float* __restrict__ cnt, int Q, int K, float* __restrict__ y) {
+    const int t = blockIdx.z, k = blockIdx.y;
+    const int d = blockIdx.x * blockDim.x + threadIdx.x;
+    const size_t row = (size_t)t * K + k;
+    if (d >= K || !live[row]) return;
+    const float* ut = u + (size_t)t * Q * K + k;
+    const float* ft = f + (size_t)t * Q * K + d;
+    float s = dsum_outer(Q, (long)k * K + d, (long)K * K,
+                         [&](int q) { return ut[(size_t)q * K] * ft[(size_t)q * K]; });
+    const float c = cs[row];
+    if (sup) {
+        const float w = 1.0f / (cnt[row] + c);
+        y[row * K + d] = w * (sup[row * K + d] + s);
+    } else {
+        y[row * K + d] = s / (c < kEpsF ? kEpsF : c);
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// Row lists for one outer iteration.  mm_rows: rows that run the MM iteration (live rows, and dead
+// rows whose cached stop-test terms are incomplete); live_rows: rows whose alpha will change, i.e.
+// whose E-step terms must be recomputed.  Order inside the lists is irrelevant to the results.
+__global__ void k_build_rows(const uint8_t* __restrict__ live, const int32_t* __restrict__ cache_len, int n_rows,
+                             int n_checks, int32_t* __restrict__ mm_rows, int32_t* __restrict__ live_rows,
+                             int32_t* __restrict__ counts /* [0]=mm, [1]=live */) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n_rows) return;
+    const bool alive = live[i];
+    const bool need = alive || (n_checks > 0 && cache_len[i] < n_checks);
+    if (need) mm_rows[atomicAdd(&counts[0], 1)] = i;
+    if (alive) live_rows[atomicAdd(&counts[1], 1)] = i;
+}
+
+// ------------------------------------------------------------------------------------------
+// The hot kernel: MM iterations l0..l1 of em_dirichlet.py:157-177 for every listed row.
+// One row = one 32-lane group; its K parameters stay in registers for the whole chunk
+// (element d in register d/32 of lane d%32), the row sum is rebuilt in torch's association
+// order every iteration, and at a checkpoint iteration the row's share of
+// ||b'-b||^2 and ||b||^2 is emitted in fp64.
+//   live rows iterate in place in `alpha`;
+//   dead rows (zero-shot clusters without members) iterate with y = -10 in `beta_dead`
+//   (their alpha row must keep its old value, em_dirichlet.py:224-226) and write their stop-test
+//   terms to `cache`, which later outer iterations reuse instead of recomputing the same
+//   trajectory (same start, same y => same numbers).
+struct MMArgs {
+    float* alpha;
+    float* beta_dead;
+    const float* y;
+    const uint8_t* live;
+    int32_t* cache_len;
+    double* cache;          // [row][n_checks][2]
+    double* rowpart;        // [row][2]
+    const int32_t* rows;
+    const int32_t* n_rows;
+    const int32_t* stop;    // [B]
+    int K, rows_per_batch, chunk, l0, l1, has_check, n_checks;
+};
+
+template <int E>
+__global__ __launch_bounds__(256) void k_mm_chunk(MMArgs a) {
+    const int lane = threadIdx.x & (kGroup - 1);
+    const int group = threadIdx.x / kGroup;
+    const int groups_per_block = blockDim.x / kGroup;
+    const int n = *a.n_rows;
+    const int K = a.K;
+    for (int i = blockIdx.x * groups_per_block + group; i < n; i += gridDim.x * groups_per_block) {
+        const int row = a.rows[i];
+        if (a.stop[row / a.rows_per_batch]) continue;
+        const bool alive = a.live[row];
+        const float* src = a.alpha;
+        float* dst = a.alpha;
+        if (!alive) {
+            if (!a.has_check || a.cache_len[row] != a.chunk) continue;
+            src = a.chunk == 0 ? a.alpha : a.beta_dead;
+            dst = a.beta_dead;
+        }
+        float beta[E], yv[E];
+#pragma unroll
+        for (int e = 0; e < E; e++) {
+            const int d = e * kGroup + lane;
+            const bool ok = d < K;
+            beta[e] = ok ? src[(size_t)row * K + d] : 0.0f;
+            yv[e] = ok ? (alive ? a.y[(size_t)row * K + d] : -10.0f) : 0.0f;
+        }
+        double num = 0.0, den = 0.0;
+        for (int l = a.l0; l <= a.l1; l++) {
+            const float s = group_sum_torch<E>(beta, K, lane);
+            const float psi_s = digamma_f32(s);
+            const bool check = a.has_check && l == a.l1;
+#pragma unroll
+            for (int e = 0; e < E; e++) {
+                const int d = e * kGroup + lane;
+                if (d < K) {
+                    const float nb = mm_update(beta[e], yv[e], psi_s);
+                    if (check) {
+                        const double df = (double)nb - (double)beta[e];
+                        num += df * df;
+                        den += (double)beta[e] * (double)beta[e];
+                    }
+                    beta[e] = nb;
+                }
+            }
+        }
+#pragma unroll
+        for (int e = 0; e < E; e++) {
+            const int d = e * kGroup + lane;
+            if (d < K) dst[(size_t)row * K + d] = beta[e];
+        }
+        if (a.has_check) {
+            num = group_sum_f64(num);
+            den = group_sum_f64(den);
+            if (lane == 0) {
+                if (alive) {
+                    a.rowpart[2 * (size_t)row] = num;
+                    a.rowpart[2 * (size_t)row + 1] = den;
+                } else {
+                    double* c = a.cache + ((size_t)row * a.n_checks + a.chunk) * 2;
+                    c[0] = num;
+                    c[1] = den;
+                    a.cache_len[row] = a.chunk + 1;
+                }
+            }
+        }
+    }
+}
+
+// Batch-global stop test (em_dirichlet.py:169-175), one block per batch:
+//   crit = ||b'-b||_F^2 / ||b||_F^2 over all N*K*K entries of the batch;  stop if < 1e-11.
+// fp64 accumulation in a fixed order; the final arithmetic follows the reference's fp32 form
+// norm()**2 / norm()**2.  Also records the number of MM iterations executed.
+__global__ __launch_bounds__(1024) void k_mm_decide(const double* __restrict__ rowpart, const double* __restrict__ cache,
+                                                    const uint8_t* __restrict__ live, int rows_per_batch, int n_checks,
+                                                    int chunk, int has_check, int l1, int is_last, int iter_mm,
+                                                    int32_t* __restrict__ stop, int32_t* __restrict__ mm_iters_out /* [B] slot of this outer iteration, stride given */,
+                                                    int mm_stride) {
+    const int b = blockIdx.x;
+    if (stop[b]) return;
+    __shared__ double sh[2][1024];
+    double num = 0.0, den = 0.0;
+    if (has_check) {
+        const size_t base = (size_t)b * rows_per_batch;
+        for (int r = threadIdx.x; r < rows_per_batch; r += blockDim.x) {
+            const size_t row = base + r;
+            if (live[row]) {
+                num += rowpart[2 * row];
+                den += rowpart[2 * row + 1];
+            } else {
+                num += cache[(row * n_checks + chunk) * 2];
+                den += cache[(row * n_checks + chunk) * 2 + 1];
+            }
+        }
+    }
+    sh[0][threadIdx.x] = num;
+    sh[1][threadIdx.x] = den;
+    __syncthreads();
+    for (int s = blockDim.x / 2; s > 0; s >>= 1) {
+        if ((int)threadIdx.x < s) {
+            sh[0][threadIdx.x] += sh[0][threadIdx.x + s];
+            sh[1][threadIdx.x] += sh[1][threadIdx.x + s];
+        }
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) {
+        bool stopped = false;
+        if (has_check) {
+            const float nn = (float)__builtin_sqrt(sh[0][0]), dn = (float)__builtin_sqrt(sh[1][0]);
+            const float crit = (nn * nn) / (dn * dn);
+            if (crit < 1e-11f) {
+                stop[b] = 1;
+                mm_iters_out[(size_t)b * mm_stride] = l1 + 1;
+                stopped = true;
+            }
+        }
+        if (!stopped && is_last) mm_iters_out[(size_t)b * mm_stride] = iter_mm;
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// E-step, part 1: per row  lgamma(sum_d alpha) + (-sum_d lgamma(alpha_d))     (em_dirichlet.py:35-36)
+template <int E>
+__global__ __launch_bounds__(256) void k_row_consts(const float* __restrict__ alpha, const int32_t* __restrict__ rows,
+                                                    const int32_t* __restrict__ n_rows, int K,
+                                                    float* __restrict__ rowc) {
+    const int lane = threadIdx.x & (kGroup - 1);
+    const int groups_per_block = blockDim.x / kGroup;
+    const int n = *n_rows;
+    for (int i = blockIdx.x * groups_per_block + threadIdx.x / kGroup; i < n; i += gridDim.x * groups_per_block) {
+        const int row = rows[i];
+        float av[E], lg[E];
+#pragma unroll
+        for (int e = 0; e < E; e++) {
+            const int d = e * kGroup + lane;
+            const bool ok = d < K;
+            av[e] = ok ? alpha[(size_t)row * K + d] : 0.0f;
+            lg[e] = ok ? lgamma_f32(av[e]) : 0.0f;
+        }
+        const float l1 = lgamma_f32(group_sum_torch<E>(av, K, lane));
+        const float l2 = -group_sum_torch<E>(lg, K, lane);
+        if (lane == 0) rowc[row] = l1 + l2;
+    }
+}
+
+// E-step, part 2: logit0[t,q,k] = rowc[t,k] + sum_d (alpha[t,k,d]-1) * logz[t,q,d]   (em_dirichlet.py:37-39)
+// One block per row; its 8 groups sweep the queries with the alpha row held in registers.
+template <int E>
+__global__ __launch_bounds__(256) void k_logits(const float* __restrict__ alpha, const float* __restrict__ logz,
+                                                const float* __restrict__ rowc, const int32_t* __restrict__ rows,
+                                                const int32_t* __restrict__ n_rows, int Q, int K,
+                                                float* __restrict__ logit0) {
+    const int lane = threadIdx.x & (kGroup - 1);
+    const int group = threadIdx.x / kGroup, groups_per_block = blockDim.x / kGroup;
+    const int n = *n_rows;
+    for (int i = blockIdx.x; i < n; i += gridDim.x) {
+        const int row = rows[i];
+        const int t = row / K, k = row % K;
+        float am1[E];
+#pragma unroll
+        for (int e = 0; e < E; e++) {
+            const int d = e * kGroup + lane;
+            am1[e] = d < K ? alpha[(size_t)row * K + d] - 1.0f : 0.0f;
+        }
+        const float rc = rowc[row];
+        for (int q = group; q < Q; q += groups_per_block) {
+            const float* lz = logz + ((size_t)t * Q + q) * K;
+            float pr[E];
+#pragma unroll
+            for (int e = 0; e < E; e++) {
+                const int d = e * kGroup + lane;
+                pr[e] = d < K ? am1[e] * lz[d] : 0.0f;
+            }
+            const float l3 = group_sum_torch<E>(pr, K, lane);
+            if (lane == 0) logit0[((size_t)t * Q + q) * K + k] = rc + l3;
+        }
+    }
+}
+
+// E-step, part 3: u = softmax_k(logit0 + (lambd * v) / Q), torch CPU softmax order
+// (max, Sleef expf of the shifted row, 16-lane strided sum + butterfly, one reciprocal).
+// One 16-lane group per (task, query) row.  Also argmax (first maximum) and the hard one-hot.
+__global__ __launch_bounds__(256) void k_softmax(const float* __restrict__ logit0, const float* __restrict__ v, int TQ,
+                                                 int Q, int K, float lambd, int hard, float* __restrict__ u,
+                                                 int32_t* __restrict__ preds) {
+    const int lane = threadIdx.x & 15;
+    const int r = (blockIdx.x * blockDim.x + threadIdx.x) >> 4;
+    if (r >= TQ) return;
+    const int t = r / Q;
+    const float* x = logit0 + (size_t)r * K;
+    const float* vt = v + (size_t)t * K;
+    float* ur = u + (size_t)r * K;
+    const float qf = (float)Q;
+    float mx = -__builtin_inff();
+    for (int k = lane; k < K; k += 16) {
+        const float val = x[k] + (lambd * vt[k]) / qf;
+        ur[k] = val;
+        mx = val > mx ? val : mx;
+    }
+#pragma unroll
+    for (int m = 8; m >= 1; m >>= 1) {
+        const float o = __shfl_xor(mx, m, 16);
+        mx = o > mx ? o : mx;
+    }
+    float acc = 0.0f;
+    bool first = true;
+    for (int k = lane; k < K; k += 16) {
+        const float ev = exp_f32_sleef(ur[k] - mx);
+        ur[k] = ev;
+        acc = first ? ev : acc + ev;
+        first = false;
+    }
+    float total;
+    if (K < 16) {   // vec_reduce_all on a partial vector: serial over the elements
+        total = __shfl(acc, 0, 16);
+        for (int k = 1; k < K; k++) total += __shfl(acc, k, 16);
+    } else {
+#pragma unroll
+        for (int m = 8; m >= 1; m >>= 1) acc += __shfl_xor(acc, m, 16);
+        total = acc;
+    }
+    const float inv = 1.0f / total;
+    float best = -1.0f;
+    int best_k = 0x7fffffff;
+    for (int k = lane; k < K; k += 16) {
+        const float uv = ur[k] * inv;
+        ur[k] = uv;
+        if (uv > best) { best = uv; best_k = k; }
+    }
+#pragma unroll
+    for (int m = 8; m >= 1; m >>= 1) {
+        const float ob = __shfl_xor(best, m, 16);
+        const int ok = __shfl_xor(best_k, m, 16);
+        if (ob > best || (ob == best && ok < best_k)) { best = ob; best_k = ok; }
+    }
+    if (hard)
+        for (int k = lane; k < K; k += 16) ur[k] = (k == best_k) ? 1.0f : 0.0f;
+    if (lane == 0) preds[r] = best_k;
+}
+
+// ------------------------------------------------------------------------------------------
+// Convergence record (em_dirichlet.py:236-239): per task ||alpha_old - alpha||_F / ||alpha_old||_F,
+// then alpha_old <- alpha.  One block per task, fp64 accumulation.
+__global__ __launch_bounds__(256) void k_criterion(const float* __restrict__ alpha, float* __restrict__ alpha_old, int K,
+                                                   float* __restrict__ ratio) {
+    const int t = blockIdx.x;
+    const size_t n = (size_t)K * K, base = (size_t)t * n;
+    double a = 0.0, b = 0.0;
+    for (size_t i = threadIdx.x; i < n; i += blockDim.x) {
+        const float o = alpha_old[base + i], c = alpha[base + i];
+        const double d = (double)o - (double)c;
+        a += d * d;
+        b += (double)o * (double)o;
+        alpha_old[base + i] = c;
+    }
+    __shared__ double sh[2][256];
+    sh[0][threadIdx.x] = a;
+    sh[1][threadIdx.x] = b;
+    __syncthreads();
+    for (int s = blockDim.x / 2; s > 0; s >>= 1) {
+        if ((int)threadIdx.x < s) {
+            sh[0][threadIdx.x] += sh[0][threadIdx.x + s];
+            sh[1][threadIdx.x] += sh[1][threadIdx.x + s];
+        }
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) ratio[t] = (float)__builtin_sqrt(sh[0][0]) / (float)__builtin_sqrt(sh[1][0]);
+}
+
+__global__ void k_criterion_mean(const float* __restrict__ ratio, int N, int force_zero, float* __restrict__ out, int stride) {
+    const int b = blockIdx.x;
+    if (threadIdx.x != 0) return;
+    const float* r = ratio + (size_t)b * N;
+    const float s = dsum_inner_serial(N, [&](int i) { return r[i]; });
+    out[(size_t)b * stride] = force_zero ? 0.0f : s / (float)N;
+}
+
+// ------------------------------------------------------------------------------------------
+// Accuracy tail helpers.
+__global__ void k_one_hot(const int32_t* __restrict__ preds, size_t TQ, int K, float* __restrict__ hot) {
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < TQ * K; i += (size_t)gridDim.x * blockDim.x)
+        hot[i] = ((int)(i % K) == preds[i / K]) ? 1.0f : 0.0f;
+}
+
+// Clusters present in preds[t,:] in first-appearance order (utils.py:387-394) and their
+// prototype rows copied out of the dense [T,K,K] statistics.
+__global__ void k_gather_prototypes(const int32_t* __restrict__ preds, const float* __restrict__ dense, int Q, int K,
+                                    int Cmax, int32_t* __restrict__ n_clusters, int32_t* __restrict__ cluster_ids,
+                                    float* __restrict__ protos) {
+    const int t = blockIdx.x;
+    __shared__ int ids[1024];
+    __shared__ int cnt;
+    if (threadIdx.x == 0) {
+        int c = 0;
+        for (int q = 0; q < Q; q++) {
+            const int p = preds[(size_t)t * Q + q];
+            bool seen = false;
+            for (int i = 0; i < c; i++) seen |= ids[i] == p;
+            if (!seen) ids[c++] = p;
+        }
+        cnt = c;
+        n_clusters[t] = c;
+        for (int i = 0; i < Cmax; i++) cluster_ids[(size_t)t * Cmax + i] = i < c ? ids[i] : -1;
+    }
+    __syncthreads();
+    const int c = cnt;
+    for (int i = threadIdx.x; i < c * K; i += blockDim.x) {
+        const int ci = i / K, d = i % K;
+        protos[((size_t)t * Cmax + ci) * K + d] = dense[((size_t)t * K + ids[ci]) * K + d];
+    }
+}
+
+__global__ void k_gather_rows(const float* __restrict__ table, int64_t n_rows, int K, const int64_t* __restrict__ idx,
+                              int64_t n_out, float* __restrict__ out) {
+    const int64_t r = blockIdx.x;
+    if (r >= n_out) return;
+    const int64_t src = idx[r];
+    if (src < 0 || src >= n_rows) return;
+    for (int d = threadIdx.x; d < K; d += blockDim.x) out[r * K + d] = table[src * K + d];
+}
+
+// ------------------------------------------------------------------------------------------
+// host side
+thread_local char g_err[512] = "";
+
+static int fail(int code, const char* fmt, const char* detail = "") {
+    snprintf(g_err, sizeof g_err, fmt, detail);
+    return code;
+}
+
+#define TCLIP_HIP(call)                                                                     \
+    do {                                                                                    \
+        hipError_t e_ = (call);                                                             \
+        if (e_ != hipSuccess) return fail(TCLIP_ERR_HIP, #call ": %s", hipGetErrorString(e_)); \
+    } while (0)
+
+static size_t align_up(size_t x) { return (x + 255) & ~(size_t)255; }
+
+struct Layout {
+    size_t logz, y, alpha_old, beta_dead, sup, cnt, cs, live, rowc, logit0, cache, cache_len, rowpart, mm_rows,
+        live_rows, counts, stop, ratio, total;
+    int n_checks;
+};
+
+static int n_chunks_of(int iter_mm) { return iter_mm <= 51 ? 1 : 1 + (iter_mm - 51 + 49) / 50; }
+static int n_checks_of(int iter_mm) { return iter_mm <= 50 ? 0 : (iter_mm - 1) / 50; }
+
+static Layout make_layout(const tclip_problem& p) {
+    Layout L;
+    const size_t T = (size_t)p.n_batches * p.tasks_per_batch, K = p.n_class, Q = p.n_query;
+    const bool zs = p.n_support == 0;
+    L.n_checks = n_checks_of(p.iter_mm);
+    size_t o = 0;
+    auto take = [&](size_t bytes) { size_t r = o; o += align_up(bytes); return r; };
+    L.logz = take(T * Q * K * 4);
+    L.y = take(T * K * K * 4);
+    L.alpha_old = take(T * K * K * 4);
+    L.beta_dead = take(zs ? T * K * K * 4 : 0);
+    L.sup = take(zs ? 0 : T * K * K * 4);
+    L.cnt = take(zs ? 0 : T * K * 4);
+    L.cs = take(T * K * 4);
+    L.live = take(T * K);
+    L.rowc = take(T * K * 4);
+    L.logit0 = take(T * Q * K * 4);
+    L.cache = take(zs ? T * K * (size_t)L.n_checks * 16 : 0);
+    L.cache_len = take(T * K * 4);
+    L.rowpart = take(T * K * 16);
+    L.mm_rows = take(T * K * 4);
+    L.live_rows = take(T * K * 4);
+    L.counts = take(256);
+    L.stop = take((size_t)p.n_batches * 4);
+    L.ratio = take(T * 4);
+    L.total = o;
+    return L;
+}
+
+static int check_problem(const tclip_problem* p) {
+    if (!p) return fail(TCLIP_ERR_ARG, "problem is null");
+    if (p->n_batches < 1 || p->tasks_per_batch < 1 || p->n_query < 1 || p->iters < 0 || p->iter_mm < 1 ||
+        p->n_support < 0)
+        return fail(TCLIP_ERR_ARG, "non-positive size in tclip_problem");
+    if (p->n_class < 2 || p->n_class > 1024) return fail(TCLIP_ERR_ARG, "n_class must be in 2..1024");
+    if ((size_t)p->n_batches * p->tasks_per_batch * p->n_class > 0x7fffffffu)
+        return fail(TCLIP_ERR_ARG, "n_batches*tasks_per_batch*n_class must fit in int32");
+    return TCLIP_OK;
+}
+
+template <template <int> class Launcher, typename... Args>
+static void dispatch_E(int K, Args... args) {
+    const int need = (K + kGroup - 1) / kGroup;
+    if (need <= 1) Launcher<1>::run(args...);
+    else if (need <= 2) Launcher<2>::run(args...);
+    else if (need <= 3) Launcher<3>::run(args...);
+    else if (need <= 4) Launcher<4>::run(args...);
+    else if (need <= 6) Launcher<6>::run(args...);
+    else if (need <= 8) Launcher<8>::run(args...);
+    else if (need <= 10) Launcher<10>::run(args...);
+    else if (need <= 13) Launcher<13>::run(args...);
+    else if (need <= 16) Launcher<16>::run(args...);
+    else if (need <= 20) Launcher<20>::run(args...);
+    else if (need <= 24) Launcher<24>::run(args...);
+    else if (need <= 28) Launcher<28>::run(args...);
+    else Launcher<32>::run(args...);
+}
+
+template <int E> struct LaunchMM {
+    static void run(int grid, hipStream_t st, MMArgs a) { hipLaunchKernelGGL(k_mm_chunk<E>, dim3(grid), dim3(256), 0, st, a); }
+};
+template <int E> struct LaunchRowConsts {
+    static void run(int grid, hipStream_t st, const float* alpha, const int32_t* rows, const int32_t* n, int K, float* rowc) {
+        hipLaunchKernelGGL(k_row_consts<E>, dim3(grid), dim3(256), 0, st, alpha, rows, n, K, rowc);
+    }
+};
+template <int E> struct LaunchLogits {
+    static void run(int grid, hipStream_t st, const float* alpha, const float* logz, const float* rowc,
+                    const int32_t* rows, const int32_t* n, int Q, int K, float* logit0) {
+        hipLaunchKernelGGL(k_logits<E>, dim3(grid), dim3(256), 0, st, alpha, logz, rowc, rows, n, Q, K, logit0);
+    }
+};
+
+static int ew_grid(size_t n) {
+    size_t g = (n + 255) / 256;
+    return (int)(g > 8192 ? 8192 : (g < 1 ? 1 : g));
+}
+
+}  // namespace tclip
+
+using namespace tclip;
+
+extern "C" {
+
+int tclip_abi_version(void) { return TCLIP_ABI_VERSION; }
+const char* tclip_last_error(void) { return g_err; }
+
+size_t tclip_workspace_bytes(const tclip_problem* p) {
+    if (check_problem(p) != TCLIP_OK) return 0;
+    return make_layout(*p).total;
+}
+
+int tclip_em_dirichlet_run(const tclip_problem* pp, const float* x_q, const float* x_s, const int64_t* y_s, float* u,
+                           float* v, float* alpha, int32_t* preds, float* criterions, int32_t* mm_iters,
+                           void* workspace, size_t workspace_bytes, void* stream) {
+    if (int rc = check_problem(pp)) return rc;
+    const tclip_problem p = *pp;
+    const bool zs = p.n_support == 0;
+    if (!x_q || !u || !v || !alpha || !preds || !criterions || !mm_iters || !workspace)
+        return fail(TCLIP_ERR_ARG, "null pointer argument");
+    if (zs != (x_s == nullptr) || zs != (y_s == nullptr))
+        return fail(TCLIP_ERR_ARG, "x_s and y_s must be given exactly when n_support > 0");
+    const Layout L = make_layout(p);
+    if (workspace_bytes < L.total) return fail(TCLIP_ERR_WORKSPACE, "workspace smaller than tclip_workspace_bytes()");
+    if (((uintptr_t)workspace & 255) != 0) return fail(TCLIP_ERR_WORKSPACE, "workspace must be 256-byte aligned");
+    hipStream_t st = (hipStream_t)stream;
+    char* ws = (char*)workspace;
+    const int B = p.n_batches, N = p.tasks_per_batch, Q = p.n_query, K = p.n_class, S = p.n_support;
+    const int T = B * N, TK = T * K;
+    const size_t TQK = (size_t)T * Q * K, TKK = (size_t)T * K * K;
+    float* logz = (float*)(ws + L.logz);
+    float* y = (float*)(ws + L.y);
+    float* alpha_old = (float*)(ws + L.alpha_old);
+    float* beta_dead = zs ? (float*)(ws + L.beta_dead) : nullptr;
+    float* sup = zs ? nullptr : (float*)(ws + L.sup);
+    float* cnt = zs ? nullptr : (float*)(ws + L.cnt);
+    float* cs = (float*)(ws + L.cs);
+    uint8_t* live = (uint8_t*)(ws + L.live);
+    float* rowc = (float*)(ws + L.rowc);
+    float* logit0 = (float*)(ws + L.logit0);
+    double* cache = zs ? (double*)(ws + L.cache) : nullptr;
+    int32_t* cache_len = (int32_t*)(ws + L.cache_len);
+    double* rowpart = (double*)(ws + L.rowpart);
+    int32_t* mm_rows = (int32_t*)(ws + L.mm_rows);
+    int32_t* live_rows = (int32_t*)(ws + L.live_rows);
+    int32_t* counts = (int32_t*)(ws + L.counts);
+    int32_t* stop = (int32_t*)(ws + L.stop);
+    float* ratio = (float*)(ws + L.ratio);
+    const int n_chunks = n_chunks_of(p.iter_mm);
+    const int n_checks = zs ? L.n_checks : 0;   // few-shot has no dead rows: nothing to cache
+
+    // ---- initialisation (em_dirichlet.py:195-211)
+    hipLaunchKernelGGL(k_log_features, dim3(ew_grid(TQK)), dim3(256), 0, st, x_q, logz, TQK);
+    hipLaunchKernelGGL(k_copy, dim3(ew_grid(TQK)), dim3(256), 0, st, x_q, u, TQK);
+    hipLaunchKernelGGL(k_fill, dim3(ew_grid(TKK)), dim3(256), 0, st, alpha, 1.0f, TKK);
+    hipLaunchKernelGGL(k_fill, dim3(ew_grid(TKK)), dim3(256), 0, st, alpha_old, 1.0f, TKK);
+    hipLaunchKernelGGL(k_fill, dim3(ew_grid(TK)), dim3(256), 0, st, v, 0.0f, (size_t)TK);
+    TCLIP_HIP(hipMemsetAsync(cache_len, 0, (size_t)TK * 4, st));
+    if (!zs) {
+        hipLaunchKernelGGL(k_support_stats, dim3(K, T), dim3(128), (size_t)S * sizeof(int), st, x_s, y_s, S, K, sup, cnt);
+    }
+    // E-step terms of the initial alpha = 1 for every row (rows that never come alive keep them):
+    // use the full-row list 0..TK-1 once.
+    {
+        // live_rows <- identity, counts[1] <- TK
+        TCLIP_HIP(hipMemsetAsync(counts, 0, 256, st));
+        TCLIP_HIP(hipMemsetAsync(live, 1, (size_t)TK, st));
+        hipLaunchKernelGGL(k_build_rows, dim3((TK + 255) / 256), dim3(256), 0, st, live, cache_len, TK, 0, mm_rows,
+                           live_rows, counts);
+        const int g8 = (TK + 7) / 8 > 65535 * 8 ? 65535 * 8 : (TK + 7) / 8;
+        dispatch_E<LaunchRowConsts>(K, g8, st, (const float*)alpha, (const int32_t*)live_rows, (const int32_t*)(counts + 1), K, rowc);
+        dispatch_E<LaunchLogits>(K, TK > 262144 ? 262144 : TK, st, (const float*)alpha, (const float*)logz, (const float*)rowc,
+                                 (const int32_t*)live_rows, (const int32_t*)(counts + 1), Q, K, logit0);
+    }
+
+    for (int it = 0; it < p.iters; it++) {
+        // ---- M-step statistics
+        hipLaunchKernelGGL(k_cluster_sizes, dim3((TK + 255) / 256), dim3(256), 0, st, (const float*)u, T, Q, K, zs ? 1 : 0,
+                           cs, live, v, cache_len);
+        hipLaunchKernelGGL(k_mstats, dim3((K + 63) / 64, K, T), dim3(64), 0, st, (const float*)u, (const float*)logz,
+                           (const float*)cs, (const uint8_t*)live, (const float*)sup, (const float*)cnt, Q, K, y);
+        TCLIP_HIP(hipMemsetAsync(counts, 0, 256, st));
+        TCLIP_HIP(hipMemsetAsync(stop, 0, (size_t)B * 4, st));
+        hipLaunchKernelGGL(k_build_rows, dim3((TK + 255) / 256), dim3(256), 0, st, (const uint8_t*)live,
+                           (const int32_t*)cache_len, TK, n_checks, mm_rows, live_rows, counts);
+        // ---- MM fixed point in chunks aligned with the stop-test checkpoints
+        for (int c = 0; c < n_chunks; c++) {
+            MMArgs a;
+            a.alpha = alpha; a.beta_dead = beta_dead; a.y = y; a.live = live; a.cache_len = cache_len;
+            a.cache = cache; a.rowpart = rowpart; a.rows = mm_rows; a.n_rows = counts; a.stop = stop;
+            a.K = K; a.rows_per_batch = N * K; a.chunk = c;
+            a.l0 = c == 0 ? 0 : 50 * c + 1;
+            a.l1 = 50 * (c + 1) < p.iter_mm - 1 ? 50 * (c + 1) : p.iter_mm - 1;
+            a.has_check = (a.l1 > 0 && a.l1 % 50 == 0) ? 1 : 0;
+            a.n_checks = n_checks > 0 ? n_checks : 1;
+            int grid = (TK + 7) / 8;
+            if (grid > 256 * 16) grid = 256 * 16;
+            dispatch_E<LaunchMM>(K, grid, st, a);
+            hipLaunchKernelGGL(k_mm_decide, dim3(B), dim3(1024), 0, st, (const double*)rowpart, (const double*)cache,
+                               (const uint8_t*)live, N * K, a.n_checks, c, a.has_check, a.l1, c == n_chunks - 1 ? 1 : 0,
+                               p.iter_mm, stop, mm_iters + it, p.iters);
+        }
+        // ---- E-step for the rows whose alpha changed, softmax over all classes
+        {
+            const int g8 = (TK + 7) / 8 > 65535 * 8 ? 65535 * 8 : (TK + 7) / 8;
+            dispatch_E<LaunchRowConsts>(K, g8 > 4096 ? 4096 : g8, st, (const float*)alpha, (const int32_t*)live_rows,
+                                        (const int32_t*)(counts + 1), K, rowc);
+            dispatch_E<LaunchLogits>(K, TK > 16384 ? 16384 : TK, st, (const float*)alpha, (const float*)logz, (const float*)rowc,
+                                     (const int32_t*)live_rows, (const int32_t*)(counts + 1), Q, K, logit0);
+        }
+        hipLaunchKernelGGL(k_softmax, dim3((T * Q * 16 + 255) / 256), dim3(256), 0, st, (const float*)logit0, (const float*)v,
+                           T * Q, Q, K, (float)p.lambd, p.hard, u, preds);
+        // ---- convergence record
+        hipLaunchKernelGGL(k_criterion, dim3(T), dim3(256), 0, st, (const float*)alpha, alpha_old, K, ratio);
+        hipLaunchKernelGGL(k_criterion_mean, dim3(B), dim3(64), 0, st, (const float*)ratio, N, (!zs && p.hard) ? 1 : 0,
+                           criterions + it, p.iters);
+    }
+    TCLIP_HIP(hipGetLastError());
+    return TCLIP_OK;
+}
+
+size_t tclip_prototype_workspace_bytes(int32_t T, int32_t Q, int32_t K) {
+    if (T < 1 || Q < 1 || K < 2) return 0;
+    return align_up((size_t)T * Q * K * 4) + align_up((size_t)T * K * K * 4) + align_up((size_t)T * K * 4) +
+           align_up((size_t)T * K);
+}
+
+int tclip_cluster_prototypes(int32_t T, int32_t Q, int32_t K, const float* x_q, const int32_t* preds,
+                             int32_t* n_clusters, int32_t* cluster_ids, float* prototypes, void* workspace,
+                             size_t workspace_bytes, void* stream) {
+    if (T < 1 || Q < 1 || K < 2 || K > 1024 || !x_q || !preds || !n_clusters || !cluster_ids || !prototypes || !workspace)
+        return fail(TCLIP_ERR_ARG, "bad argument to tclip_cluster_prototypes");
+    if (workspace_bytes < tclip_prototype_workspace_bytes(T, Q, K)) return fail(TCLIP_ERR_WORKSPACE, "workspace too small");
+    hipStream_t st = (hipStream_t)stream;
+    char* ws = (char*)workspace;
+    float* hot = (float*)ws;
+    float* dense = (float*)(ws + align_up((size_t)T * Q * K * 4));
+    float* cs = (float*)((char*)dense + align_up((size_t)T * K * K * 4));
+    uint8_t* live = (uint8_t*)((char*)cs + align_up((size_t)T * K * 4));
+    const int TK = T * K;
+    const int Cmax = Q < K ? Q : K;
+    hipLaunchKernelGGL(k_one_hot, dim3(ew_grid((size_t)T * Q * K)), dim3(256), 0, st, preds, (size_t)T * Q, K, hot);
+    // cluster sizes of the one-hot predictions; "live" = non-empty cluster
+    hipLaunchKernelGGL(k_cluster_sizes, dim3((TK + 255) / 256), dim3(256), 0, st, (const float*)hot, T, Q, K, 1, cs, live,
+                       (float*)nullptr, (int32_t*)nullptr);
+    hipLaunchKernelGGL(k_mstats, dim3((K + 63) / 64, K, T), dim3(64), 0, st, (const float*)hot, x_q, (const float*)cs,
+                       (const uint8_t*)live, (const float*)nullptr, (const float*)nullptr, Q, K, dense);
+    hipLaunchKernelGGL(k_gather_prototypes, dim3(T), dim3(256), 0, st, preds, (const float*)dense, Q, K, Cmax, n_clusters,
+                       cluster_ids, prototypes);
+    TCLIP_HIP(hipGetLastError());
+    return TCLIP_OK;
+}
+
+int tclip_gather_rows(const float* table, int64_t n_rows, int32_t K, const int64_t* idx, int64_t n_out, float* out,
+                      void* stream) {
+    if (!table || !idx || !out || n_rows < 1 || K < 1 || n_out < 0) return fail(TCLIP_ERR_ARG, "bad argument to tclip_gather_rows");
+    if (n_out == 0) return TCLIP_OK;
+    hipLaunchKernelGGL(k_gather_rows, dim3((unsigned)n_out), dim3(128), 0, (hipStream_t)stream, table, n_rows, K, idx, n_out, out);
+    TCLIP_HIP(hipGetLastError());
+    return TCLIP_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,116 @@
+"""Host-side driver of the HIP engine: torch tensors in, torch tensors out.
+
+PyTorch is plumbing here (device memory through its caching allocator, the current HIP stream);
+every number is produced by libtclip.so.  One call handles n_batches independent reference
+batches (the MM stop test couples the tasks of one batch, so the batch is the
+unit of parity and of multi-GPU sharding)."""
+import ctypes
+
+import torch
+
+from . import _capi
+
+
+def _ptr(t):
+    return ctypes.c_void_p(t.data_ptr()) if t is not None else None
+
+
+def _stream():
+    return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def _require_cuda(t, name):
+    if not t.is_cuda:
+        raise RuntimeError(f"{name} must live on the GPU: the EM-Dirichlet engine has no CPU path")
+
+
+class EMDirichletResult:
+    __slots__ = ("u", "v", "alpha", "preds", "criterions", "mm_iters")
+
+    def __init__(self, **kw):
+        for k, val in kw.items():
+            setattr(self, k, val)
+
+
+def run_em_dirichlet(x_q, x_s=None, y_s=None, *, n_batches=1, iters, iter_mm=1000, lambd, hard=False):
+    """x_q (T,Q,K) f32 cuda with T = n_batches * tasks_per_batch; x_s (T,S,K), y_s (T,S) for few-shot.
+
+    Returns EMDirichletResult of cuda tensors; nothing is synchronised."""
+    _require_cuda(x_q, "x_q")
+    x_q = x_q.contiguous().float()
+    T, Q, K = x_q.shape
+    if T % n_batches:
+        raise ValueError("number of tasks must be a multiple of n_batches")
+    few = x_s is not None
+    S = 0
+    if few:
+        _require_cuda(x_s, "x_s")
+        x_s = x_s.contiguous().float()
+        y_s = y_s.to(x_q.device).long().reshape(T, -1).contiguous()
+        S = x_s.shape[1]
+    dev = x_q.device
+    p = _capi.Problem(n_batches, T // n_batches, Q, K, S, iters, iter_mm, int(lambd), int(bool(hard)))
+    lib = _capi.lib()
+    ws_bytes = lib.tclip_workspace_bytes(ctypes.byref(p))
+    if ws_bytes == 0:
+        raise RuntimeError("tclip_workspace_bytes rejected the problem: " + lib.tclip_last_error().decode())
+    with torch.cuda.device(dev):
+        ws = torch.empty(ws_bytes + 256, dtype=torch.uint8, device=dev)
+        off = (-ws.data_ptr()) % 256
+        u = torch.empty(T, Q, K, device=dev)
+        v = torch.empty(T, K, device=dev)
+        alpha = torch.empty(T, K, K, device=dev)
+        preds = torch.empty(T, Q, dtype=torch.int32, device=dev)
+        crit = torch.zeros(n_batches, max(iters, 1), device=dev)[:, :iters].contiguous()
+        mm = torch.zeros(n_batches, max(iters, 1), dtype=torch.int32, device=dev)[:, :iters].contiguous()
+        rc = lib.tclip_em_dirichlet_run(ctypes.byref(p), _ptr(x_q), _ptr(x_s), _ptr(y_s), _ptr(u), _ptr(v), _ptr(alpha),
+                                        _ptr(preds), _ptr(crit), _ptr(mm), ctypes.c_void_p(ws.data_ptr() + off),
+                                        ws_bytes, _stream())
+        _capi.check(rc, "tclip_em_dirichlet_run")
+        # keep the workspace alive until the stream has consumed it
+        ws.record_stream(torch.cuda.current_stream())
+    return EMDirichletResult(u=u, v=v, alpha=alpha, preds=preds, criterions=crit, mm_iters=mm)
+
+
+def clustering_accuracy(x_q, preds, y_q, graph_matching=True):
+    """Zero-shot accuracy tail: device prototypes of the predicted clusters, host assignment.
+
+    x_q (T,Q,K) cuda f32, preds (T,Q) cuda i32, y_q (T,Q) int64 (any device).
+    Returns (acc (T,) f32 cpu, new_preds (T,Q) i32 cpu)."""
+    _require_cuda(x_q, "x_q")
+    x_q = x_q.contiguous().float()
+    T, Q, K = x_q.shape
+    dev = x_q.device
+    lib = _capi.lib()
+    cmax = min(Q, K)
+    with torch.cuda.device(dev):
+        ws_bytes = lib.tclip_prototype_workspace_bytes(T, Q, K)
+        ws = torch.empty(ws_bytes + 256, dtype=torch.uint8, device=dev)
+        off = (-ws.data_ptr()) % 256
+        n_clusters = torch.empty(T, dtype=torch.int32, device=dev)
+        ids = torch.empty(T, cmax, dtype=torch.int32, device=dev)
+        protos = torch.zeros(T, cmax, K, device=dev)
+        preds = preds.to(dev).int().contiguous()
+        rc = lib.tclip_cluster_prototypes(T, Q, K, _ptr(x_q), _ptr(preds), _ptr(n_clusters), _ptr(ids), _ptr(protos),
+                                          ctypes.c_void_p(ws.data_ptr() + off), ws_bytes, _stream())
+        _capi.check(rc, "tclip_cluster_prototypes")
+        preds_h, nc_h, ids_h, protos_h = preds.cpu(), n_clusters.cpu(), ids.cpu(), protos.cpu()
+    y_h = y_q.reshape(T, Q).long().cpu().contiguous()
+    new_preds = torch.empty(T, Q, dtype=torch.int32)
+    acc = torch.empty(T, dtype=torch.float32)
+    rc = lib.tclip_match_clusters_host(T, Q, K, _ptr(preds_h), _ptr(nc_h), _ptr(ids_h), _ptr(protos_h), _ptr(y_h),
+                                       int(bool(graph_matching)), _ptr(new_preds), _ptr(acc))
+    _capi.check(rc, "tclip_match_clusters_host")
+    return acc, new_preds
+
+
+def gather_rows(table, idx):
+    """table (n,K) cuda f32, idx (m,) int64 -> (m,K) cuda f32 (device-side task construction)."""
+    _require_cuda(table, "table")
+    table = table.contiguous().float()
+    idx = idx.to(table.device).long().contiguous()
+    out = torch.empty(idx.numel(), table.shape[1], device=table.device)
+    with torch.cuda.device(table.device):
+        rc = _capi.lib().tclip_gather_rows(_ptr(table), table.shape[0], table.shape[1], _ptr(idx), idx.numel(), _ptr(out), _stream())
+    _capi.check(rc, "tclip_gather_rows")
+    return out
