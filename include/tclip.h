@@ -98,6 +98,14 @@ int tclip_match_clusters_host(int32_t n_task, int32_t n_query, int32_t n_class, 
 int tclip_gather_rows(const float* table, int64_t n_rows, int32_t n_class, const int64_t* idx,
                       int64_t n_out, float* out, void* stream);
 
+/* Optional instrumentation used by bench.py (thread-local, off by default).  While enabled,
+ * every launch of the majorize-minimize kernel issued by tclip_em_dirichlet_run on this thread is
+ * bracketed by HIP events on the caller's stream and the element-updates it executes are counted
+ * on the device.  tclip_profile_collect synchronises the device, returns the summed kernel time,
+ * the number of launches and the element-update count since the last collection, and resets. */
+int tclip_profile_enable(int on);
+int tclip_profile_collect(double* mm_kernel_ms, int64_t* mm_launches, int64_t* element_updates);
+
 #ifdef __cplusplus
 }
 #endif

@@ -17,6 +17,8 @@
 #include <stdio.h>
 #include <string.h>
 
+#include <vector>
+
 #include "../../include/tclip.h"
 #include "tclip_device.h"
 
@@ -236,6 +238,7 @@ struct MMArgs {
     const int32_t* rows;
     const int32_t* n_rows;
     const int32_t* stop;    // [B]
+    unsigned long long* work_counter;   // optional: element-updates executed (instrumentation)
     int K, rows_per_batch, chunk, l0, l1, has_check, n_checks;
 };
 
@@ -289,6 +292,8 @@ __global__ __launch_bounds__(256) void k_mm_chunk(MMArgs a) {
             const int d = e * kGroup + lane;
             if (d < K) dst[(size_t)row * K + d] = beta[e];
         }
+        if (a.work_counter && lane == 0)
+            atomicAdd(a.work_counter, (unsigned long long)K * (unsigned long long)(a.l1 - a.l0 + 1));
         if (a.has_check) {
             num = group_sum_f64(num);
             den = group_sum_f64(den);
@@ -576,6 +581,25 @@ static int fail(int code, const char* fmt, const char* detail = "") {
 
 static size_t align_up(size_t x) { return (x + 255) & ~(size_t)255; }
 
+// Optional instrumentation (bench.py): HIP events around every k_mm_chunk launch and a device
+// counter of executed element-updates.  Thread-local, off by default, never touched otherwise.
+struct Profile {
+    bool on = false;
+    std::vector<hipEvent_t> ev;      // start/stop pairs, reused across collections
+    size_t used = 0;
+    unsigned long long* counter = nullptr;
+};
+thread_local Profile g_prof;
+
+static hipEvent_t prof_event() {
+    if (g_prof.used == g_prof.ev.size()) {
+        hipEvent_t e;
+        if (hipEventCreate(&e) != hipSuccess) return nullptr;
+        g_prof.ev.push_back(e);
+    }
+    return g_prof.ev[g_prof.used++];
+}
+
 struct Layout {
     size_t logz, y, alpha_old, beta_dead, sup, cnt, cs, live, rowc, logit0, cache, cache_len, rowpart, mm_rows,
         live_rows, counts, stop, ratio, total;
@@ -760,9 +784,13 @@ int tclip_em_dirichlet_run(const tclip_problem* pp, const float* x_q, const floa
             a.l1 = 50 * (c + 1) < p.iter_mm - 1 ? 50 * (c + 1) : p.iter_mm - 1;
             a.has_check = (a.l1 > 0 && a.l1 % 50 == 0) ? 1 : 0;
             a.n_checks = n_checks > 0 ? n_checks : 1;
+            a.work_counter = g_prof.on ? g_prof.counter : nullptr;
             int grid = (TK + 7) / 8;
             if (grid > 256 * 16) grid = 256 * 16;
+            hipEvent_t e0 = g_prof.on ? prof_event() : nullptr, e1 = g_prof.on ? prof_event() : nullptr;
+            if (e0 && e1) TCLIP_HIP(hipEventRecord(e0, st));
             dispatch_E<LaunchMM>(K, grid, st, a);
+            if (e0 && e1) TCLIP_HIP(hipEventRecord(e1, st));
             hipLaunchKernelGGL(k_mm_decide, dim3(B), dim3(1024), 0, st, (const double*)rowpart, (const double*)cache,
                                (const uint8_t*)live, N * K, a.n_checks, c, a.has_check, a.l1, c == n_chunks - 1 ? 1 : 0,
                                p.iter_mm, stop, mm_iters + it, p.iters);
@@ -783,6 +811,35 @@ int tclip_em_dirichlet_run(const tclip_problem* pp, const float* x_q, const floa
                            criterions + it, p.iters);
     }
     TCLIP_HIP(hipGetLastError());
+    return TCLIP_OK;
+}
+
+int tclip_profile_enable(int on) {
+    if (on && !g_prof.counter) {
+        TCLIP_HIP(hipMalloc((void**)&g_prof.counter, sizeof(unsigned long long)));
+        TCLIP_HIP(hipMemset(g_prof.counter, 0, sizeof(unsigned long long)));
+    }
+    g_prof.on = on != 0;
+    return TCLIP_OK;
+}
+
+int tclip_profile_collect(double* mm_kernel_ms, int64_t* mm_launches, int64_t* element_updates) {
+    TCLIP_HIP(hipDeviceSynchronize());
+    double ms = 0.0;
+    for (size_t i = 0; i + 1 < g_prof.used; i += 2) {
+        float t = 0.f;
+        TCLIP_HIP(hipEventElapsedTime(&t, g_prof.ev[i], g_prof.ev[i + 1]));
+        ms += t;
+    }
+    if (mm_kernel_ms) *mm_kernel_ms = ms;
+    if (mm_launches) *mm_launches = (int64_t)(g_prof.used / 2);
+    unsigned long long c = 0;
+    if (g_prof.counter) {
+        TCLIP_HIP(hipMemcpy(&c, g_prof.counter, sizeof c, hipMemcpyDeviceToHost));
+        TCLIP_HIP(hipMemset(g_prof.counter, 0, sizeof c));
+    }
+    if (element_updates) *element_updates = (int64_t)c;
+    g_prof.used = 0;
     return TCLIP_OK;
 }
 

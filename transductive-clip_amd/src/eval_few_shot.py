@@ -1,0 +1,85 @@
+"""Task-batch loop of the few-shot evaluation (reference: src/eval_few_shot.py:213-270) on the
+batched engine; see src/eval_zero_shot.py for the structure.  Per batch the reference draws all
+query index sets first, then all support index sets (eval_few_shot.py:233-241); the same order is
+kept so that a seeded run sees the reference's tasks."""
+import numpy as np
+import torch
+
+from src.methods.few_shot.em_dirichlet import EM_DIRICHLET
+from src.methods.few_shot.hard_em_dirichlet import HARD_EM_DIRICHLET
+from src.sampler_few_shot import CategoriesSampler_few_shot, SamplerQuery_few_shot, SamplerSupport_few_shot
+from src.task_generator_few_shot import relabel
+from src.utils import Logger, compute_confidence_interval
+from tclip_amd import engine, sharding
+
+_METHODS = {'EM_DIRICHLET': EM_DIRICHLET, 'HARD_EM_DIRICHLET': HARD_EM_DIRICHLET}
+
+
+class Evaluator_few_shot:
+    def __init__(self, device, args, log_file):
+        self.device = device
+        self.args = args
+        self.log_file = log_file
+        self.logger = Logger(__name__, self.log_file)
+
+    def run_full_evaluation(self, model, preprocess):
+        raise NotImplementedError("CLIP feature extraction is outside this package: extract the "
+                                  "softmax features with the reference and call evaluate_tasks()")
+
+    def get_method_builder(self, model, device, args, log_file):
+        try:
+            cls = _METHODS[args.name_method]
+        except KeyError:
+            raise ValueError(f"method {args.name_method!r} is not part of the EM-Dirichlet engine")
+        return cls(model=model, device=device, log_file=log_file, args=args)
+
+    def sample_indices(self, all_labels_support, all_labels_query):
+        a = self.args
+        q_all, s_all = [], []
+        for _ in range(int(a.number_tasks / a.batch_size)):
+            sampler = CategoriesSampler_few_shot(a.batch_size, a.k_eff, a.n_class, a.shots, a.n_query,
+                                                 force_query_size=True)
+            sampler.create_list_classes(all_labels_support, all_labels_query)
+            q_all.append(torch.stack(list(SamplerQuery_few_shot(sampler)), 0))
+            s_all.append(torch.stack(list(SamplerSupport_few_shot(sampler)), 0))
+        return torch.stack(s_all, 0), torch.stack(q_all, 0)
+
+    def evaluate_tasks(self, model, all_features_support, all_labels_support, all_features_query, all_labels_query):
+        a = self.args
+        self.logger.info("=> Runnning evaluation with method {} on {} dataset".format(
+            a.name_method, getattr(a, 'used_test_set', 'test')))
+        s_idx, q_idx = self.sample_indices(all_labels_support, all_labels_query)
+        n_batches, N, S = s_idx.shape
+        Q = q_idx.shape[2]
+        mine = sharding.my_batches(n_batches)
+        dev = torch.device(self.device)
+        tab_s = torch.as_tensor(all_features_support).float().to(dev)
+        tab_q = torch.as_tensor(all_features_query).float().to(dev)
+        lab_s = torch.as_tensor(np.asarray(all_labels_support)).long()
+        lab_q = torch.as_tensor(np.asarray(all_labels_query)).long()
+        K = tab_q.shape[1]
+        si, qi = s_idx[mine].reshape(-1), q_idx[mine].reshape(-1)
+        x_s = engine.gather_rows(tab_s, si).view(len(mine) * N, S, K)
+        x_q = engine.gather_rows(tab_q, qi).view(len(mine) * N, Q, K)
+        y_s, y_q = lab_s[si].view(-1, S), lab_q[qi].view(-1, Q)
+        # label re-indexing / column permutation of Tasks_Generator_few_shot.get_task, per task
+        xs2, xq2, ys2, yq2 = [], [], [], []
+        for t in range(x_s.shape[0]):
+            a_, b_, c_, d_ = relabel(x_s[t], x_q[t], y_s[t], y_q[t], a.use_softmax_feature)
+            xs2.append(a_)
+            xq2.append(b_)
+            ys2.append(c_)
+            yq2.append(d_)
+        x_s, x_q = torch.stack(xs2, 0), torch.stack(xq2, 0)
+        y_s, y_q = torch.stack(ys2, 0), torch.stack(yq2, 0)
+        method = self.get_method_builder(model=model, device=self.device, args=a, log_file=self.log_file)
+        method.run_method(support=x_s, query=x_q, y_s=y_s.to(dev), y_q=y_q.to(dev), n_batches=len(mine))
+        logs = method.get_logs()
+        acc = torch.from_numpy(logs['acc'][:, -1].copy()).view(len(mine), N).to(dev)
+        acc = sharding.gather_batch_results(acc, n_batches)
+        self.last_method = method
+        if acc is None:
+            return None, None
+        acc = acc.cpu().numpy()
+        results_task = [compute_confidence_interval(acc[b])[0] for b in range(n_batches)]
+        return np.asarray(results_task).mean(), float(logs['timestamps'])

@@ -1,0 +1,75 @@
+"""Task-batch loop of the zero-shot evaluation (reference: src/eval_zero_shot.py:140-187),
+rebuilt around the batched engine: the index tensors of ALL batches are drawn first (the method
+itself consumes no random numbers, so the reference's RNG stream is reproduced), the feature
+table lives on the GPU, rows are gathered there, and every batch of this rank runs in one engine
+call with n_batches > 1 (each batch keeps its own MM stop test).  With torch.distributed
+initialised, batches are dealt round-robin to the ranks and gathered once onto rank 0.
+
+Feature extraction, dataset handling and result files of the reference's Evaluator are out of
+scope (they need CLIP weights and images); run_full_evaluation says so."""
+import numpy as np
+import torch
+
+from src.methods.zero_shot.em_dirichlet import EM_DIRICHLET
+from src.methods.zero_shot.hard_em_dirichlet import HARD_EM_DIRICHLET
+from src.sampler_zero_shot import CategoriesSampler_zero_shot, SamplerQuery_zero_shot
+from src.utils import Logger, compute_confidence_interval
+from tclip_amd import engine, sharding
+
+_METHODS = {'EM_DIRICHLET': EM_DIRICHLET, 'HARD_EM_DIRICHLET': HARD_EM_DIRICHLET}
+
+
+class Evaluator_zero_shot:
+    def __init__(self, device, args, log_file):
+        self.device = device
+        self.args = args
+        self.log_file = log_file
+        self.logger = Logger(__name__, self.log_file)
+
+    def run_full_evaluation(self, model, preprocess):
+        raise NotImplementedError("CLIP feature extraction is outside this package: extract the "
+                                  "softmax features with the reference and call evaluate_tasks()")
+
+    def get_method_builder(self, model, device, args, log_file):
+        try:
+            cls = _METHODS[args.name_method]
+        except KeyError:
+            raise ValueError(f"method {args.name_method!r} is not part of the EM-Dirichlet engine")
+        return cls(model=model, device=device, log_file=log_file, args=args)
+
+    def sample_indices(self, all_labels_query):
+        """(n_batches, batch_size, n_query) int64 index tensor, drawn batch by batch exactly as
+        the reference does (a fresh sampler per batch)."""
+        a = self.args
+        out = []
+        for _ in range(int(a.number_tasks / a.batch_size)):
+            sampler = CategoriesSampler_zero_shot(a.batch_size, a.k_eff, a.n_class, a.n_query, force_query_size=True)
+            sampler.create_list_classes(all_labels_query)
+            out.append(torch.stack(list(SamplerQuery_zero_shot(sampler)), 0))
+        return torch.stack(out, 0)
+
+    def evaluate_tasks(self, model, all_features_query, all_labels_query):
+        a = self.args
+        self.logger.info("=> Runnning evaluation with method {} on {} dataset".format(
+            a.name_method, getattr(a, 'used_test_set', 'test')))
+        idx = self.sample_indices(all_labels_query)                 # every rank draws the same stream
+        n_batches, N, Q = idx.shape
+        mine = sharding.my_batches(n_batches)
+        dev = torch.device(self.device)
+        table = torch.as_tensor(all_features_query).float().to(dev)
+        labels = torch.as_tensor(np.asarray(all_labels_query)).long()
+        my_idx = idx[mine].reshape(-1)
+        K = table.shape[1]
+        x_q = engine.gather_rows(table, my_idx).view(len(mine) * N, Q, K)
+        y_q = labels[my_idx].view(len(mine) * N, Q)
+        method = self.get_method_builder(model=model, device=self.device, args=a, log_file=self.log_file)
+        method.run_method(query=x_q, y_q=y_q.to(dev), n_batches=len(mine))
+        logs = method.get_logs()
+        acc = torch.from_numpy(logs['acc'][:, -1].copy()).view(len(mine), N).to(dev)
+        acc = sharding.gather_batch_results(acc, n_batches)
+        self.last_method = method
+        if acc is None:                                             # not rank 0
+            return None, None
+        acc = acc.cpu().numpy()
+        results_task = [compute_confidence_interval(acc[b])[0] for b in range(n_batches)]
+        return np.asarray(results_task).mean(), float(logs['timestamps'])

@@ -23,6 +23,9 @@ _SIGNATURES = {
     "tclip_cluster_prototypes": (ctypes.c_int, [ctypes.c_int32] * 3 + [_P] * 6 + [ctypes.c_size_t, _P]),
     "tclip_match_clusters_host": (ctypes.c_int, [ctypes.c_int32] * 3 + [_P] * 5 + [ctypes.c_int32, _P, _P]),
     "tclip_gather_rows": (ctypes.c_int, [_P, ctypes.c_int64, ctypes.c_int32, _P, ctypes.c_int64, _P, _P]),
+    "tclip_profile_enable": (ctypes.c_int, [ctypes.c_int]),
+    "tclip_profile_collect": (ctypes.c_int, [ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_int64),
+                                             ctypes.POINTER(ctypes.c_int64)]),
 }
 EXPORTS = tuple(_SIGNATURES)
 _lib = None
@@ -35,6 +38,14 @@ def lib():
             raise RuntimeError(
                 f"{LIB_PATH} is missing: build it with `python transductive-clip_amd/build.py` "
                 "(there is no CPU or PyTorch fallback for the EM-Dirichlet path)")
+        # torch must be loaded first: libtclip.so needs libamdhip64.so.7 and has to bind to the ONE
+        # HIP runtime of the process, the copy bundled with torch (same SONAME).  Loaded the other
+        # way round, /opt/rocm's copy and torch's copy would both be live and streams, events and
+        # synchronisation would no longer be shared.
+        import torch  # noqa: F401
+        hip_rt = os.path.join(os.path.dirname(torch.__file__), "lib", "libamdhip64.so")
+        if os.path.exists(hip_rt):
+            ctypes.CDLL(hip_rt, mode=ctypes.RTLD_GLOBAL)
         l = ctypes.CDLL(LIB_PATH)
         for name, (res, args) in _SIGNATURES.items():
             fn = getattr(l, name)

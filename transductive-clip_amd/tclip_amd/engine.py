@@ -114,3 +114,15 @@ def gather_rows(table, idx):
         rc = _capi.lib().tclip_gather_rows(_ptr(table), table.shape[0], table.shape[1], _ptr(idx), idx.numel(), _ptr(out), _stream())
     _capi.check(rc, "tclip_gather_rows")
     return out
+
+
+def profile_enable(on=True):
+    _capi.check(_capi.lib().tclip_profile_enable(int(bool(on))), "tclip_profile_enable")
+
+
+def profile_collect():
+    """(mm_kernel_ms, mm_launches, element_updates) since the last call; synchronises the device."""
+    ms, n, upd = ctypes.c_double(0), ctypes.c_int64(0), ctypes.c_int64(0)
+    _capi.check(_capi.lib().tclip_profile_collect(ctypes.byref(ms), ctypes.byref(n), ctypes.byref(upd)),
+                "tclip_profile_collect")
+    return ms.value, n.value, upd.value
