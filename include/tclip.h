@@ -106,6 +106,16 @@ int tclip_gather_rows(const float* table, int64_t n_rows, int32_t n_class, const
 int tclip_profile_enable(int on);
 int tclip_profile_collect(double* mm_kernel_ms, int64_t* mm_launches, int64_t* element_updates);
 
+/* Device self-test (used by tests/test_gpu_primitives.py): compares the fast correctly rounded
+ * fp32 reciprocal / square root / quotient of csrc/tclip_math.h and the fused digamma-lgamma
+ * routine with the compiler's IEEE operators and the generic routines, on the GPU.
+ * mismatches host [7] out: {rcp (3 x 2^23 arguments, exhaustive binade), sqrt (2 x 2^24),
+ * quotient (3 x 2^28 pairs), digamma (2 x 2^24), lgamma (2^24; informational: differences there
+ * are fp64 double-rounding cases), rcp with ONE refinement step (2^23; informational), whole MM
+ * update branch-free vs generic (2^24; differences = the lgamma cases)}.
+ * Allocates 56 bytes of device memory for the counters. */
+int tclip_selftest_primitives(uint64_t* mismatches);
+
 #ifdef __cplusplus
 }
 #endif

@@ -134,9 +134,8 @@ inline void mm_step_row(const float* beta, const float* y, float* next, int K) {
     const float psi_s = tclip::digamma_f32(s);
     for (int d = 0; d < K; d++) {
         const float a = beta[d];
-        const float x1 = a + 1.0f;
-        const float psi1 = tclip::digamma_f32(x1);
-        const float lg1 = tclip::lgamma_f32(x1);
+        float psi1, lg1;
+        tclip::digamma_lgamma_xp1(a, tclip::kLogTab, psi1, lg1);
         float curv;
         if (a > 1e-11f) {
             float t = (0.0f - lg1) + psi1 * a;

@@ -156,7 +156,22 @@ __device__ float dsum_inner_serial(int n, F get) {
 
 // One majorize-minimize update of a single Dirichlet parameter (em_dirichlet.py:153-167):
 // the operation order, the roundings (no contraction) and the special functions of torch CPU.
-__device__ __forceinline__ float mm_update(float a, float y, float psi_s) {
+// Branch-free (selects only) so that the elements a lane holds interleave; valid for
+// mm_fast_domain(a) and finite y, psi_s.
+__device__ __forceinline__ float mm_update(float a, float y, float psi_s, const LogTabEntry* tab) {
+    float psi1, lg1;
+    digamma_lgamma_xp1(a, tab, psi1, lg1);
+    const float t = (0.0f - lg1) + psi1 * a;
+    const float big = __builtin_fabsf(div_rn_inrange_f32(2.0f * t, a * a));
+    const float curv = (a > 1e-11f) ? big : 1.6449340668482264f;   // polygamma(1, 1)
+    float b = (psi1 - psi_s) - curv * a;
+    b = b - y;
+    const float delta = b * b + 4.0f * curv;
+    return div_rn_inrange_f32(-b + sqrt_rn_inrange_f32(delta), 2.0f * curv);
+}
+
+// The same update with the generic routines and the compiler's IEEE operators: any input.
+__device__ __noinline__ float mm_update_generic(float a, float y, float psi_s) {
     const float x1 = a + 1.0f;
     const float psi1 = digamma_f32(x1);
     const float lg1 = lgamma_f32(x1);
@@ -165,12 +180,18 @@ __device__ __forceinline__ float mm_update(float a, float y, float psi_s) {
         const float t = (0.0f - lg1) + psi1 * a;
         curv = __builtin_fabsf((2.0f * t) / (a * a));
     } else {
-        curv = 1.6449340668482264f;  // polygamma(1, 1)
+        curv = 1.6449340668482264f;
     }
     float b = (psi1 - psi_s) - curv * a;
     b = b - y;
     const float delta = b * b + 4.0f * curv;
     return (-b + __builtin_sqrtf(delta)) / (2.0f * curv);
+}
+
+// The 16-entry log table in LDS (one copy per workgroup).
+__device__ __forceinline__ void load_log_table(LogTabEntry* lds_tab) {
+    if (threadIdx.x < 16) lds_tab[threadIdx.x] = kLogTab[threadIdx.x];
+    __syncthreads();
 }
 
 }  // namespace tclip

@@ -201,6 +201,228 @@ TCLIP_HD float lgamma_f32(float x) {
 }
 
 // ---------------------------------------------------------------------------------------------
+// Correctly rounded fp32 reciprocal / quotient / square root from the 1-ulp hardware
+// approximations plus FMA residual corrections (Markstein-style).  On gfx950 these replace the
+// compiler's generic IEEE expansions (v_div_scale/v_div_fmas/v_div_fixup, ~12 instructions each)
+// on the hot path; tests/test_gpu_primitives.py checks them on the device against the IEEE
+// operators, exhaustively over a binade for rcp and sqrt.  Preconditions: operands positive and
+// normal with exponents in [-60, 60] (true on the MM path: arguments are alpha+1, alpha^2,
+// 2*curvature, b^2+4*curvature; the callers fall back to the IEEE operator outside that range).
+// On the host the IEEE operators are used directly.
+// v_rcp_f32 (1 ulp) + ONE residual correction: the device self-test finds it equal to the IEEE
+// quotient 1/x for every float of a binade (at three exponents), so a second step buys nothing.
+TCLIP_HD float rcp_rn_f32(float x) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    const float r = __builtin_amdgcn_rcpf(x);
+    const float e = __builtin_fmaf(-x, r, 1.0f);
+    return __builtin_fmaf(e, r, r);
+#else
+    return 1.0f / x;
+#endif
+}
+
+// Two correction steps (kept for the self-test's comparison).
+TCLIP_HD float rcp_rn2_f32(float x) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    float r = __builtin_amdgcn_rcpf(x);
+    float e = __builtin_fmaf(-x, r, 1.0f);
+    r = __builtin_fmaf(e, r, r);
+    e = __builtin_fmaf(-x, r, 1.0f);
+    return __builtin_fmaf(e, r, r);
+#else
+    return 1.0f / x;
+#endif
+}
+
+// Branch-free forms for operands known to be in range (see the MM-path domain note at
+// digamma_lgamma_xp1): no range test, no IEEE fallback.
+TCLIP_HD float div_rn_inrange_f32(float a, float b) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    const float r = rcp_rn_f32(b);
+    const float q = a * r;
+    const float rem = __builtin_fmaf(-b, q, a);
+    return __builtin_fmaf(rem, r, q);
+#else
+    return a / b;
+#endif
+}
+
+TCLIP_HD float sqrt_rn_inrange_f32(float x) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    const float y = __builtin_amdgcn_rsqf(x);
+    float s = x * y, h = 0.5f * y;
+    const float e = __builtin_fmaf(-h, s, 0.5f);
+    s = __builtin_fmaf(s, e, s);
+    h = __builtin_fmaf(h, e, h);
+    const float d = __builtin_fmaf(-s, s, x);
+    s = __builtin_fmaf(d, h, s);
+    const float d2 = __builtin_fmaf(-s, s, x);
+    return __builtin_fmaf(d2, h, s);
+#else
+    return __builtin_sqrtf(x);
+#endif
+}
+
+TCLIP_HD bool fast_range_f32(float x) {   // positive normal, |exponent| <= 60
+    const uint32_t b = f32_bits(x);
+    return b >= 0x21800000u && b <= 0x5d800000u;
+}
+
+TCLIP_HD float div_rn_f32(float a, float b) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    if (fast_range_f32(b) && fast_range_f32(__builtin_fabsf(a))) {
+        const float r = rcp_rn_f32(b);
+        const float q = a * r;
+        const float rem = __builtin_fmaf(-b, q, a);
+        return __builtin_fmaf(rem, r, q);
+    }
+#endif
+    return a / b;
+}
+
+TCLIP_HD float sqrt_rn_f32(float x) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    if (fast_range_f32(x)) {
+        const float y = __builtin_amdgcn_rsqf(x);
+        float s = x * y, h = 0.5f * y;
+        const float e = __builtin_fmaf(-h, s, 0.5f);
+        s = __builtin_fmaf(s, e, s);
+        h = __builtin_fmaf(h, e, h);
+        const float d = __builtin_fmaf(-s, s, x);
+        s = __builtin_fmaf(d, h, s);
+        const float d2 = __builtin_fmaf(-s, s, x);
+        return __builtin_fmaf(d2, h, s);
+    }
+#endif
+    return __builtin_sqrtf(x);
+}
+
+TCLIP_HD void log_reduce_tab(float x, const LogTabEntry* tab, double& r, double& y0) {
+    const uint32_t ix = f32_bits(x);
+    const uint32_t tmp = ix - 0x3f330000u;
+    const int i = (tmp >> 19) & 15;
+    const int k = (int32_t)tmp >> 23;
+    const double z = (double)bits_f32(ix - (tmp & 0xff800000u));
+    const LogTabEntry t = tab[i];
+    r = __builtin_fma(z, t.invc, -1.0);
+    y0 = t.logc + (double)k * kLn2;
+}
+
+TCLIP_HD double log_f64_tab(double v, const LogTabEntry* tab) {
+    const uint64_t iv = f64_bits(v);
+    const uint32_t tmp = (uint32_t)(iv >> 32) - 0x3fe66000u;
+    const int i = (tmp >> 16) & 15;
+    const int k = (int32_t)tmp >> 20;
+    const double z = bits_f64(iv - ((uint64_t)(tmp & 0xfff00000u) << 32));
+    const LogTabEntry t = tab[i];
+    const double r = __builtin_fma(z, t.invc, -1.0);
+    return (t.logc + (double)k * kLn2) + log1p_small(r);
+}
+
+// digamma_f32 for positive finite arguments with the fast reciprocal (row sums of alpha).
+TCLIP_HD float digamma_pos_f32(float x, const LogTabEntry* tab) {
+    if (!fast_range_f32(x) || !fast_range_f32(x * x)) return digamma_f32(x);
+    float acc = 0.0f;
+    while (x < 10.0f) {
+        acc -= rcp_rn_f32(x);
+        x += 1.0f;
+    }
+    if (x == 10.0f) return acc + 2.25175258906672110764f;
+    const float rx = rcp_rn_f32(x), z = rcp_rn_f32(x * x);
+    float p = 8.33333333333333333333E-2f;
+    p = __builtin_fmaf(p, z, -2.10927960927960927961E-2f);
+    p = __builtin_fmaf(p, z, 7.57575757575757575758E-3f);
+    p = __builtin_fmaf(p, z, -4.16666666666666666667E-3f);
+    p = __builtin_fmaf(p, z, 3.96825396825396825397E-3f);
+    p = __builtin_fmaf(p, z, -8.33333333333333333333E-3f);
+    p = __builtin_fmaf(p, z, 8.33333333333333333333E-2f);
+    double r, y0;
+    log_reduce_tab(x, tab, r, y0);
+    const double r2 = r * r;
+    double yl = __builtin_fma(0x1.5575b0be00b6ap-2, r, -0x1.ffffef20a4123p-2);
+    yl = __builtin_fma(-0x1.00ea348b88334p-2, r2, yl);
+    yl = __builtin_fma(yl, r2, y0 + r);
+    return acc + (float)yl - (0.5f * rx) - z * p;
+}
+
+// ---------------------------------------------------------------------------------------------
+// The two special functions of one MM update, fused:  psi1 = digamma(a+1) exactly as
+// digamma_f32 computes it, lg1 = lgamma(a+1) exactly as lgamma_f32 computes it, for a >= 0.
+// Straight-line code (9 predicated recurrence steps, no data-dependent branches) so that the
+// compiler can interleave the independent elements a lane holds; one table reduction serves
+// logf(x) of the digamma series, log(x) of Stirling's formula and, re-indexed, log of the
+// recurrence product.  `tab` is the 16-entry log table (LDS copy on the device).
+// Domain of the branch-free form: 0 <= a <= 2^40 (then x = a+1, x*x, the reciprocals and every
+// intermediate stay normal); callers route anything else (NaN, inf, negative, huge) to the generic
+// digamma_f32 / lgamma_f32.
+TCLIP_HD bool mm_fast_domain(float a) { return a >= 0.0f && a <= 0x1p40f; }
+
+TCLIP_HD void digamma_lgamma_xp1(float a, const LogTabEntry* tab, float& psi1, float& lg1) {
+    float x = a + 1.0f;
+    const double xd0 = (double)x;
+    double prod = 1.0;
+    float acc = 0.0f, nf = 0.0f;
+#if defined(__HIP_DEVICE_COMPILE__)
+#pragma unroll
+#endif
+    for (int j = 0; j < 9; j++) {                            // while (x < 10) {acc -= 1/x; x += 1}
+        const bool small = x < 10.0f;
+        const float rxj = rcp_rn_f32(x);
+        acc -= small ? rxj : 0.0f;
+        prod *= small ? xd0 + (double)j : 1.0;               // exact shifts for the lgamma recurrence
+        const float inc = small ? 1.0f : 0.0f;
+        x += inc;
+        nf += inc;
+    }
+    const double xd = xd0 + (double)nf;
+    // digamma: asymptotic series at x >= 10 (the x == 10 case returns the tabulated psi(10))
+    const float xx = x * x;
+    const float rx = rcp_rn_f32(x);
+    const float z = rcp_rn_f32(xx);                          // x <= 2^40 + 9 < 1e17: always the series
+    float p = 8.33333333333333333333E-2f;
+    p = __builtin_fmaf(p, z, -2.10927960927960927961E-2f);
+    p = __builtin_fmaf(p, z, 7.57575757575757575758E-3f);
+    p = __builtin_fmaf(p, z, -4.16666666666666666667E-3f);
+    p = __builtin_fmaf(p, z, 3.96825396825396825397E-3f);
+    p = __builtin_fmaf(p, z, -8.33333333333333333333E-3f);
+    p = __builtin_fmaf(p, z, 8.33333333333333333333E-2f);
+    const float yser = z * p;
+    double r, y0;
+    log_reduce_tab(x, tab, r, y0);
+    const double r2 = r * r;
+    double yl = __builtin_fma(0x1.5575b0be00b6ap-2, r, -0x1.ffffef20a4123p-2);   // glibc logf polynomial
+    yl = __builtin_fma(-0x1.00ea348b88334p-2, r2, yl);
+    yl = __builtin_fma(yl, r2, y0 + r);
+    const float logx = (float)yl;                            // x >= 10 here, never 1.0
+    const float asym = acc + logx - (0.5f * rx) - yser;     // 0.5f/x == 0.5f*RN(1/x): scaling by 2 is exact
+    psi1 = (x == 10.0f) ? acc + 2.25175258906672110764f : asym;
+    // lgamma(a+1) = Stirling(xd) - log(prod), all in fp64, rounded once
+    const double xf = (double)x;
+    double t = (double)rx;                                   // ~1/xd to 1e-6: two Newton steps
+    t = t * __builtin_fma(-xd, t, 2.0);
+    t = t * __builtin_fma(-xd, t, 2.0);
+    const double dl = (xd - xf) * t;                         // log(xd) = log(x) + log1p((xd-x)/x)
+    const double lxd = (y0 + log1p_small(r)) + __builtin_fma(-0.5 * dl, dl, dl);
+    const double t2 = t * t;
+    double st = 1.0 / 1188.0;
+    st = __builtin_fma(st, t2, -1.0 / 1680.0);
+    st = __builtin_fma(st, t2, 1.0 / 1260.0);
+    st = __builtin_fma(st, t2, -1.0 / 360.0);
+    st = __builtin_fma(st, t2, 1.0 / 12.0);
+    double lg = __builtin_fma(xd - 0.5, lxd, -xd) + 0.91893853320467274178 + st * t;
+    lg -= log_f64_tab(prod, tab);
+    // a < 2^-10: Stirling minus log-product cancels 12.8 - 12.8 and keeps only ~1e-15 absolute;
+    // the Taylor series of lgamma(1+a) = -gamma a + sum_k (-1)^k zeta(k) a^k / k is exact to fp64 there
+    const double ad = (double)a;
+    double ser = 0.20738555102867398527;                          //  zeta(5)/5
+    ser = __builtin_fma(ser, ad, -0.27058080842778454788);        // -zeta(4)/4
+    ser = __builtin_fma(ser, ad, 0.40068563438653142847);         //  zeta(3)/3
+    ser = __builtin_fma(ser, ad, -0.82246703342411321824);        // -zeta(2)/2
+    ser = __builtin_fma(ser, ad, -0.57721566490153286061);        // -gamma
+    lg1 = (float)(a < 0x1p-10f ? ser * ad : lg);
+}
+
+// ---------------------------------------------------------------------------------------------
 // expf as Sleef expf_u10 computes it (torch softmax on CPU goes through Vectorized::exp):
 // Cody-Waite reduction by ln2 in two fp32 pieces, degree-5 polynomial, all fused.
 TCLIP_HD float exp_f32_sleef(float d) {
