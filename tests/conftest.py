@@ -16,7 +16,9 @@ def pytest_configure(config):
 
 
 def golden_names(prefix=""):
-    return sorted(f[:-4] for f in os.listdir(GOLDEN) if f.endswith(".npz") and f.startswith(prefix))
+    """method-level fixtures (the eval_* files pin the task-batch loop and have another schema)"""
+    return sorted(f[:-4] for f in os.listdir(GOLDEN)
+                  if f.endswith(".npz") and f.startswith(prefix) and not f.startswith("eval_"))
 
 
 @pytest.fixture(scope="session")

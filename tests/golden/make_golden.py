@@ -21,8 +21,14 @@ import torch
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(os.path.dirname(HERE))
-sys.path.insert(0, os.path.join(ROOT, "transductive-clip_amd"))
-from tclip_amd import synth  # noqa: E402
+# The product package also has a top-level `src/` (it mirrors the reference's module names), so it
+# must NOT be importable while the reference is: load the synthetic-data module by file path.
+import importlib.util  # noqa: E402
+_spec = importlib.util.spec_from_file_location(
+    "tclip_synth", os.path.join(ROOT, "transductive-clip_amd", "tclip_amd", "synth.py"))
+synth = importlib.util.module_from_spec(_spec)
+_spec.loader.exec_module(synth)
+sys.path[:] = [p for p in sys.path if "transductive-clip_amd" not in p]
 
 for _m in ("clip", "torchvision", "torchvision.transforms"):
     sys.modules.setdefault(_m, types.ModuleType(_m))

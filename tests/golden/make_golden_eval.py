@@ -1,0 +1,100 @@
+#!/usr/bin/env python3
+"""Golden vectors for the task-batch loop, produced by RUNNING the
+reference's Evaluator_*.evaluate_tasks on a synthetic feature table in the build container
+(/root/reference is imported, never copied; clip/torchvision are stubbed as in make_golden.py).
+
+Seeds are set the way main.py:42-46 sets them, the sampler iterators are wrapped to record the
+index tensors they yield, and the returned (mean accuracy, mean time) is stored.
+
+    python tests/golden/make_golden_eval.py
+"""
+import os
+import random
+import sys
+import types
+
+import numpy as np
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+# The product package also has a top-level `src/` (it mirrors the reference's module names), so it
+# must NOT be importable while the reference is: load the synthetic-data module by file path.
+import importlib.util  # noqa: E402
+_spec = importlib.util.spec_from_file_location(
+    "tclip_synth", os.path.join(ROOT, "transductive-clip_amd", "tclip_amd", "synth.py"))
+synth = importlib.util.module_from_spec(_spec)
+_spec.loader.exec_module(synth)
+sys.path[:] = [p for p in sys.path if "transductive-clip_amd" not in p]
+
+for _m in ("clip", "torchvision", "torchvision.transforms"):
+    sys.modules.setdefault(_m, types.ModuleType(_m))
+REF = "/root/reference"
+
+
+class Args(dict):
+    __getattr__ = dict.__getitem__
+    __setattr__ = dict.__setitem__
+
+
+def seed_all(seed):
+    random.seed(seed)
+    torch.manual_seed(seed)
+    np.random.seed(seed)
+
+
+def record_iter(cls, store):
+    orig = cls.__iter__
+
+    def wrapped(self):
+        for item in orig(self):
+            store.append(item.clone())
+            yield item
+    cls.__iter__ = wrapped
+    return orig
+
+
+def main():
+    sys.path.insert(0, REF)
+    import src.eval_zero_shot as ez
+    import src.eval_few_shot as ef
+    sys.path.pop(0)
+    torch.set_num_threads(min(8, os.cpu_count() or 1))
+    seed = 2020
+    for kind, hard in (("zs", False), ("zs", True), ("fs", False)):
+        K = 10
+        args = Args(iter=10 if hard else 20, iter_mm=1000, num_classes_test=K, n_class=K, n_query=75, k_eff=5, T=30,
+                    use_softmax_feature=True, graph_matching=True, shots=2, number_tasks=20, batch_size=10,
+                    name_method="HARD_EM_DIRICHLET" if hard else "EM_DIRICHLET", used_test_set="test", tunable=False,
+                    method="hard_em_dirichlet" if hard else "em_dirichlet", dataset="synthetic")
+        feats, labels = synth.make_feature_table(K, 40, seed=seed)
+        out = {"kind": kind, "hard": hard, "K": K, "seed": seed, "rows_per_class": 40,
+               "number_tasks": 20, "batch_size": 10, "shots": 2}
+        seed_all(seed)
+        if kind == "zs":
+            q = []
+            o = record_iter(ez.SamplerQuery_zero_shot, q)
+            ev = ez.Evaluator_zero_shot(device=torch.device("cpu"), args=args, log_file="/tmp/golden_eval.log")
+            acc, t = ev.evaluate_tasks(None, feats, labels)
+            ez.SamplerQuery_zero_shot.__iter__ = o
+            out["query_idx"] = torch.stack(q).numpy().reshape(2, 10, 75)
+        else:
+            feats_s, labels_s = synth.make_feature_table(K, 16, seed=seed + 1)
+            q, s = [], []
+            oq = record_iter(ef.SamplerQuery_few_shot, q)
+            os_ = record_iter(ef.SamplerSupport_few_shot, s)
+            ev = ef.Evaluator_few_shot(device=torch.device("cpu"), args=args, log_file="/tmp/golden_eval.log")
+            acc, t = ev.evaluate_tasks(None, feats_s, labels_s, feats, labels)
+            ef.SamplerQuery_few_shot.__iter__ = oq
+            ef.SamplerSupport_few_shot.__iter__ = os_
+            out["query_idx"] = torch.stack(q).numpy().reshape(2, 10, 75)
+            out["support_idx"] = torch.stack(s).numpy().reshape(2, 10, -1)
+            out["support_rows_per_class"] = 16
+        out["mean_accuracy"] = np.float64(acc)
+        name = f"eval_{kind}_{'hard' if hard else 'soft'}_K10"
+        np.savez_compressed(os.path.join(HERE, name + ".npz"), **out)
+        print(name, "acc", acc, "time", t, {k: getattr(v, "shape", v) for k, v in out.items()})
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,121 @@
+"""CPU: the C-ABI library loads, exports every symbol include/tclip.h declares, validates its
+arguments without touching a GPU, and its host-side cluster matching equals scipy's."""
+import ctypes
+import os
+import re
+
+import numpy as np
+import pytest
+import torch
+from scipy.optimize import linear_sum_assignment
+
+from conftest import ROOT
+from tclip_amd import _capi
+
+
+def _declared_functions():
+    text = open(os.path.join(ROOT, "include", "tclip.h")).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(tclip_[a-z_]+)\s*\(", text)))
+
+
+def test_library_exports_every_declared_symbol():
+    lib = _capi.lib()
+    names = _declared_functions()
+    assert len(names) >= 10
+    for n in names:
+        assert hasattr(lib, n), f"{n} declared in include/tclip.h but not exported"
+    assert set(_capi.EXPORTS) == set(names)
+    assert lib.tclip_abi_version() == 1
+
+
+def test_workspace_size_and_argument_checks():
+    lib = _capi.lib()
+    p = _capi.Problem(10, 100, 75, 100, 0, 20, 1000, 1500, 0)
+    ws = lib.tclip_workspace_bytes(ctypes.byref(p))
+    # logz + logit0 (2 x T*Q*K) + y, alpha_old, beta_dead (3 x T*K*K) fp32 dominate
+    assert ws >= 4 * (2 * 1000 * 75 * 100 + 3 * 1000 * 100 * 100)
+    bad = _capi.Problem(1, 1, 75, 2000, 0, 20, 1000, 1, 0)
+    assert lib.tclip_workspace_bytes(ctypes.byref(bad)) == 0
+    assert b"n_class" in lib.tclip_last_error()
+    # null pointers are rejected before any HIP call
+    rc = lib.tclip_em_dirichlet_run(ctypes.byref(p), *([None] * 10), 0, None)
+    assert rc == 1
+
+
+def test_missing_library_fails_loudly(monkeypatch, tmp_path):
+    monkeypatch.setattr(_capi, "_lib", None)
+    monkeypatch.setattr(_capi, "LIB_PATH", str(tmp_path / "libtclip.so"))
+    with pytest.raises(RuntimeError, match="no CPU or PyTorch fallback"):
+        _capi.lib()
+
+
+def _match(preds, protos_full, y, K, graph=True):
+    lib = _capi.lib()
+    T, Q = preds.shape
+    cmax = min(Q, K)
+    ncl = np.zeros(T, np.int32)
+    ids = -np.ones((T, cmax), np.int32)
+    pr = np.zeros((T, cmax, K), np.float32)
+    for t in range(T):
+        order = []
+        for c in preds[t]:
+            if c not in order:
+                order.append(int(c))
+        ncl[t] = len(order)
+        ids[t, :len(order)] = order
+        pr[t, :len(order)] = protos_full[t, order]
+    newp = np.empty((T, Q), np.int32)
+    acc = np.empty(T, np.float32)
+    P = lambda a: a.ctypes.data_as(ctypes.c_void_p)  # noqa: E731
+    preds32 = np.ascontiguousarray(preds, np.int32)
+    y64 = np.ascontiguousarray(y, np.int64)
+    rc = lib.tclip_match_clusters_host(T, Q, K, P(preds32), P(ncl), P(ids), P(pr), P(y64), int(graph), P(newp), P(acc))
+    assert rc == 0
+    return newp, acc, ids, ncl, pr
+
+
+@pytest.mark.parametrize("K,Q,seed", [(10, 75, 0), (37, 75, 1), (100, 75, 2), (5, 75, 3), (200, 40, 4)])
+def test_cluster_matching_equals_scipy(K, Q, seed):
+    rng = np.random.default_rng(seed)
+    T = 12
+    preds = rng.integers(0, K, size=(T, Q))
+    preds[0, :] = 3 % K                                  # a single cluster
+    preds[1, :] = np.arange(Q) % K                       # as many clusters as possible
+    protos = rng.random((T, K, K)).astype(np.float32)
+    protos[2] = 0.0                                      # all-zero prototypes: pure tie-breaking
+    protos[3, :, : K // 2] = protos[3, :, K // 2: 2 * (K // 2)]   # exact ties between columns
+    y = rng.integers(0, K, size=(T, Q))
+    newp, acc, ids, ncl, pr = _match(preds, protos, y, K, graph=True)
+    for t in range(T):
+        C = ncl[t]
+        cost = -pr[t, :C].astype(np.float64)
+        _, cols = linear_sum_assignment(cost, maximize=False)
+        lut = {int(ids[t, i]): int(cols[i]) for i in range(C)}
+        want = np.array([lut[int(c)] for c in preds[t]], np.int32)
+        assert np.array_equal(newp[t], want), f"task {t}"
+        assert acc[t] == np.float32((want == y[t]).sum()) / np.float32(Q)
+    newp2, _, _, _, _ = _match(preds, protos, y, K, graph=False)
+    for t in range(T):
+        want = protos[t].argmax(-1)[preds[t]]
+        assert np.array_equal(newp2[t], want.astype(np.int32))
+
+
+def test_method_classes_keep_the_reference_contract():
+    from src.methods.few_shot.em_dirichlet import EM_DIRICHLET as FS
+    from src.methods.few_shot.hard_em_dirichlet import HARD_EM_DIRICHLET as FSH
+    from src.methods.zero_shot.em_dirichlet import EM_DIRICHLET as ZS
+    from src.methods.zero_shot.hard_em_dirichlet import HARD_EM_DIRICHLET as ZSH
+    from src.utils import CfgNode
+    a = CfgNode(iter=2, iter_mm=100, num_classes_test=20, n_class=20, n_query=75, k_eff=4, T=30,
+                use_softmax_feature=True, graph_matching=True)
+    for cls, lambd in ((ZS, 4 * 75), (ZSH, 4 * 75), (FS, 5 * 75), (FSH, 5 * 75)):
+        m = cls(model=None, device=torch.device("cpu"), log_file=None, args=a)
+        assert (m.lambd, m.iter, m.iter_mm, m.eps) == (lambd, 2, 100, 1e-15)
+    m = ZS(model=None, device=torch.device("cpu"), log_file=None, args=a)
+    task = {"x_q": torch.rand(2, 75, 20), "y_q": torch.zeros(2, 75, 1, dtype=torch.int64)}
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        m.run_task(dict(task))
+    a.use_softmax_feature = False
+    with pytest.raises(ValueError, match="unit simplex"):
+        m.run_task(dict(task))

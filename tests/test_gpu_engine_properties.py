@@ -1,0 +1,136 @@
+"""GPU: the engine against the CPU oracles on fresh seeded inputs and through size-independent
+properties at BASELINE.json's full sizes."""
+import os
+import random
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import GOLDEN
+
+pytestmark = pytest.mark.gpu
+
+
+def _fro(a, ref):
+    a, ref = a.reshape(len(a), -1).astype(np.float64), ref.reshape(len(ref), -1).astype(np.float64)
+    return np.sqrt(((a - ref) ** 2).sum(1)) / np.sqrt((ref ** 2).sum(1))
+
+
+@pytest.mark.parametrize("K,N,B,hard,few", [(12, 3, 2, False, False), (20, 4, 3, True, False), (33, 3, 2, False, False),
+                                            (7, 3, 2, False, False), (5, 2, 2, True, False),
+                                            (12, 3, 2, False, True), (16, 2, 2, True, True)])
+def test_engine_equals_cpu_oracle_on_fresh_inputs(K, N, B, hard, few):
+    """Through the C ABI with n_batches > 1, against the C++ oracle run batch by batch: identical
+    MM counts and argmax, alpha/u to 1e-6 (both sides share the special-function header, so this
+    isolates kernels, reduction orders, the on-device stop test and the dead-row machinery)."""
+    from oracle import c_oracle
+    from tclip_amd import engine, synth
+    iters, iter_mm, lambd = (5 if hard else 6), 230, int(K / 5) * 75 if K >= 5 else 75
+    x_q, _ = synth.make_query_tasks(B * N, K, seed=100 + K, k_eff=(3 if few else None))
+    x_s = y_s = None
+    if few:
+        x_s, y_s = synth.make_support(B * N, K, 3, seed=200 + K)
+    res = engine.run_em_dirichlet(x_q.cuda(), x_s.cuda() if few else None, y_s.cuda() if few else None,
+                                  n_batches=B, iters=iters, iter_mm=iter_mm, lambd=lambd, hard=hard)
+    torch.cuda.synchronize()
+    for b in range(B):
+        sl = slice(b * N, (b + 1) * N)
+        ref = c_oracle.run(x_q[sl].numpy(), x_s[sl].numpy() if few else None, y_s[sl].numpy() if few else None,
+                           iters=iters, iter_mm=iter_mm, lambd=lambd, hard=hard)
+        assert np.array_equal(res.mm_iters[b].cpu().numpy(), ref["mm_iters"])
+        assert np.array_equal(res.preds[sl].cpu().numpy(), ref["argmax"][-1].astype(np.int32))
+        assert _fro(res.alpha[sl].cpu().numpy(), ref["alpha"]).max() <= 1e-6
+        assert np.abs(res.u[sl].cpu().numpy() - ref["u"]).max() <= 1e-6
+        assert np.abs(res.v[sl].cpu().numpy() - ref["v"]).max() <= 1e-6
+        if not (few and hard):
+            np.testing.assert_allclose(res.criterions[b].cpu().numpy(), ref["criterions"], rtol=1e-4, atol=1e-7)
+        else:
+            assert (res.criterions[b].cpu().numpy() == 0).all()
+
+
+def test_batches_are_independent_and_order_free():
+    """Running batches together, separately or permuted gives bit-identical per-batch results."""
+    from tclip_amd import engine, synth
+    K, N, B = 24, 5, 4
+    x_q, _ = synth.make_query_tasks(B * N, K, seed=5)
+    x = x_q.cuda()
+    kw = dict(iters=4, iter_mm=300, lambd=int(K / 5) * 75, hard=False)
+    full = engine.run_em_dirichlet(x, n_batches=B, **kw)
+    perm = [2, 0, 3, 1]
+    xp = torch.cat([x[b * N:(b + 1) * N] for b in perm])
+    permuted = engine.run_em_dirichlet(xp, n_batches=B, **kw)
+    for i, b in enumerate(perm):
+        single = engine.run_em_dirichlet(x[b * N:(b + 1) * N], n_batches=1, **kw)
+        for name in ("alpha", "u", "v", "preds"):
+            ref = getattr(full, name)[b * N:(b + 1) * N]
+            assert torch.equal(ref, getattr(single, name))
+            assert torch.equal(ref, getattr(permuted, name)[i * N:(i + 1) * N])
+        assert torch.equal(full.mm_iters[b], single.mm_iters[0])
+
+
+def test_full_size_properties_k100_batch100():
+    """BASELINE configs[1] shape (K=100, batch of 100, full 20 x 1000 schedule): responsibilities
+    are distributions, v is consistent with u, alpha is positive and finite, dead clusters keep
+    the alpha of the iteration in which they died (checked through repeatability), counts sane."""
+    from tclip_amd import engine, synth
+    K, N = 100, 100
+    x_q, y_q = synth.make_query_tasks(N, K, seed=11)
+    x = x_q.cuda()
+    res = engine.run_em_dirichlet(x, n_batches=1, iters=20, iter_mm=1000, lambd=int(K / 5) * 75, hard=False)
+    again = engine.run_em_dirichlet(x, n_batches=1, iters=20, iter_mm=1000, lambd=int(K / 5) * 75, hard=False)
+    torch.cuda.synchronize()
+    assert torch.equal(res.alpha, again.alpha) and torch.equal(res.u, again.u)      # run-to-run deterministic
+    u = res.u
+    assert torch.isfinite(res.alpha).all() and (res.alpha > 0).all()
+    assert (u >= 0).all() and (u.sum(-1) - 1).abs().max() <= 1e-5
+    assert torch.equal(res.preds.long(), u.argmax(-1))
+    mm = res.mm_iters[0].cpu().numpy()
+    assert ((mm == 1000) | ((mm - 1) % 50 == 0)).all() and mm.max() <= 1000 and mm.min() >= 51
+    acc, newp = engine.clustering_accuracy(x, res.preds, y_q.squeeze(2))
+    assert 0.5 < float(acc.mean()) <= 1.0
+    hard = engine.run_em_dirichlet(x, n_batches=1, iters=10, iter_mm=1000, lambd=int(K / 5) * 75, hard=True)
+    assert ((hard.u == 0) | (hard.u == 1)).all() and (hard.u.sum(-1) == 1).all()
+
+
+@pytest.mark.parametrize("name", ["eval_zs_soft_K10", "eval_zs_hard_K10", "eval_fs_soft_K10"])
+def test_task_batch_loop_matches_reference(name):
+    """evaluate_tasks on the seeded synthetic table: the reference's mean accuracy (fixtures made
+    by running the reference's Evaluator_*.evaluate_tasks)."""
+    from src.utils import CfgNode
+    from tclip_amd import synth
+    g = np.load(os.path.join(GOLDEN, name + ".npz"))
+    hard, K = bool(g["hard"]), int(g["K"])
+    a = CfgNode(iter=10 if hard else 20, iter_mm=1000, num_classes_test=K, n_class=K, n_query=75, k_eff=5, T=30,
+                use_softmax_feature=True, graph_matching=True, shots=int(g["shots"]), number_tasks=int(g["number_tasks"]),
+                batch_size=int(g["batch_size"]), name_method="HARD_EM_DIRICHLET" if hard else "EM_DIRICHLET",
+                used_test_set="test")
+    feats, labels = synth.make_feature_table(K, int(g["rows_per_class"]), seed=int(g["seed"]))
+    random.seed(int(g["seed"]))
+    torch.manual_seed(int(g["seed"]))
+    np.random.seed(int(g["seed"]))
+    if str(g["kind"]) == "zs":
+        from src.eval_zero_shot import Evaluator_zero_shot
+        acc, t = Evaluator_zero_shot(torch.device("cuda:0"), a, None).evaluate_tasks(None, feats, labels)
+    else:
+        from src.eval_few_shot import Evaluator_few_shot
+        fs, ls = synth.make_feature_table(K, int(g["support_rows_per_class"]), seed=int(g["seed"]) + 1)
+        acc, t = Evaluator_few_shot(torch.device("cuda:0"), a, None).evaluate_tasks(None, fs, ls, feats, labels)
+    assert abs(float(acc) - float(g["mean_accuracy"])) < 1e-7
+    assert t > 0
+
+
+def test_method_class_drop_in_zero_shot():
+    """The reference-shaped call sequence of eval_zero_shot.py:171-180 on the GPU."""
+    from src.methods.zero_shot.hard_em_dirichlet import HARD_EM_DIRICHLET
+    from src.utils import CfgNode
+    g = np.load(os.path.join(GOLDEN, "zs_hard_K10_N4.npz"))
+    a = CfgNode(iter=10, iter_mm=1000, num_classes_test=10, n_class=10, n_query=75, k_eff=5, T=30,
+                use_softmax_feature=True, graph_matching=True)
+    method = HARD_EM_DIRICHLET(model=None, device=torch.device("cuda:0"), log_file=None, args=a)
+    logs = method.run_task(task_dic={"x_q": torch.from_numpy(g["x_q"]), "y_q": torch.from_numpy(g["y_q"])})
+    assert set(logs) == {"timestamps", "criterions", "acc"}
+    assert logs["acc"].shape == (4, 1) and logs["acc"].dtype == np.float32 and logs["criterions"].shape == (10,)
+    assert np.array_equal(logs["acc"], g["acc"])
+    assert method.u.shape == (4, 75, 10) and method.v.shape == (4, 10) and method.alpha.shape == (4, 10, 10)
+    assert method.alpha.is_cuda
