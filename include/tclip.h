@@ -106,14 +106,15 @@ int tclip_gather_rows(const float* table, int64_t n_rows, int32_t n_class, const
 int tclip_profile_enable(int on);
 int tclip_profile_collect(double* mm_kernel_ms, int64_t* mm_launches, int64_t* element_updates);
 
-/* Device self-test (used by tests/test_gpu_primitives.py): compares the fast correctly rounded
- * fp32 reciprocal / square root / quotient of csrc/tclip_math.h and the fused digamma-lgamma
- * routine with the compiler's IEEE operators and the generic routines, on the GPU.
- * mismatches host [7] out: {rcp (3 x 2^23 arguments, exhaustive binade), sqrt (2 x 2^24),
- * quotient (3 x 2^28 pairs), digamma (2 x 2^24), lgamma (2^24; informational: differences there
- * are fp64 double-rounding cases), rcp with ONE refinement step (2^23; informational), whole MM
- * update branch-free vs generic (2^24; differences = the lgamma cases)}.
- * Allocates 56 bytes of device memory for the counters. */
+/* Device self-test (used by tests/test_gpu_primitives.py).  out host [14]:
+ *   [0] 1/x: fast exact reciprocal vs IEEE quotient, every float of a binade at 3 exponents
+ *   [1] a/b: 2^29 operand pairs            [2] fused digamma(a+1), digamma of row sums vs generic
+ *   [3] fused lgamma(a+1) vs generic        [4] whole MM update, branch-free vs generic (2^24 each)
+ *   [5] 1/x with two correction steps (informational)
+ *   [6..13] 64-bit checksums of the restated library routines (digamma, lgamma, sqrt, exp, log,
+ *           fused psi, fused lgamma, digamma_pos) over the argument streams of
+ *           csrc/tclip_selftest_inputs.h; oracle/mathcheck.cpp computes the host values.
+ * [0]..[4] must be 0.  Allocates (and frees) 112 bytes of device memory for the counters. */
 int tclip_selftest_primitives(uint64_t* mismatches);
 
 #ifdef __cplusplus

@@ -1,17 +1,28 @@
 // TEST INFRASTRUCTURE: host build of the product's special-function header so that the CPU
-// test-suite can compare it, value by value, with torch's CPU implementations.  Never loaded
-// by the product path.
+// test-suite can compare it, value by value, with torch's CPU implementations, and so that the
+// GPU self-test's checksums (same functions, same pseudo-random arguments, evaluated on the
+// device) have a host value to be compared with.  Never loaded by the product path.
 #include <math.h>
 #include "../transductive-clip_amd/csrc/tclip_math.h"
+#include "../transductive-clip_amd/csrc/tclip_selftest_inputs.h"
 extern "C" {
-void mc_digamma(const float* x, float* y, long n) { for (long i = 0; i < n; i++) y[i] = tclip::digamma_f32(x[i]); }
-void mc_lgamma(const float* x, float* y, long n) { for (long i = 0; i < n; i++) y[i] = tclip::lgamma_f32(x[i]); }
-void mc_log(const float* x, float* y, long n) { for (long i = 0; i < n; i++) y[i] = tclip::log_f32(x[i]); }
-void mc_logf_glibc(const float* x, float* y, long n) { for (long i = 0; i < n; i++) y[i] = tclip::logf_glibc(x[i]); }
-void mc_libm_logf(const float* x, float* y, long n) { for (long i = 0; i < n; i++) y[i] = logf(x[i]); }
-void mc_exp(const float* x, float* y, long n) { for (long i = 0; i < n; i++) y[i] = tclip::exp_f32_sleef(x[i]); }
+#define MC_MAP(name, expr) \
+    void name(const float* x, float* y, long n) { for (long i = 0; i < n; i++) { const float v = x[i]; y[i] = (expr); } }
+MC_MAP(mc_digamma, tclip::digamma_f32(v))
+MC_MAP(mc_digamma_pos, tclip::digamma_pos_f32(v, tclip::kLogTab))
+MC_MAP(mc_lgamma, tclip::lgamma_f32(v))
+MC_MAP(mc_log, tclip::log_f32(v))
+MC_MAP(mc_logf_glibc, tclip::logf_glibc(v))
+MC_MAP(mc_libm_logf, logf(v))
+MC_MAP(mc_exp, tclip::exp_f32_sleef(v))
+MC_MAP(mc_sqrt_torch, tclip::sqrt_torch_f32(v))
+MC_MAP(mc_lgamma_cr, (float)lgamma((double)v))
 void mc_xp1_psi(const float* x, float* y, long n) { for (long i = 0; i < n; i++) { float p, l; tclip::digamma_lgamma_xp1(x[i], tclip::kLogTab, p, l); y[i] = p; } }
 void mc_xp1_lg(const float* x, float* y, long n) { for (long i = 0; i < n; i++) { float p, l; tclip::digamma_lgamma_xp1(x[i], tclip::kLogTab, p, l); y[i] = l; } }
-void mc_digamma_pos(const float* x, float* y, long n) { for (long i = 0; i < n; i++) y[i] = tclip::digamma_pos_f32(x[i], tclip::kLogTab); }
-void mc_lgamma_cr(const float* x, float* y, long n) { for (long i = 0; i < n; i++) y[i] = (float)lgamma((double)x[i]); }
+// checksums of the routines over the self-test's argument streams (see tclip_selftest_inputs.h)
+void mc_checksums(unsigned long long* out) {
+    for (int f = 0; f < tclip::kSelfTestFunctions; f++) out[f] = 0;
+    for (uint32_t i = 0; i < tclip::kSelfTestCount; i++)
+        for (int f = 0; f < tclip::kSelfTestFunctions; f++) out[f] += tclip::selftest_term(f, i, tclip::kLogTab);
+}
 }

@@ -146,7 +146,7 @@ inline void mm_step_row(const float* beta, const float* y, float* next, int K) {
         float b = (psi1 - psi_s) - curv * a;
         b = b - y[d];
         const float delta = b * b + 4.0f * curv;
-        next[d] = (-b + sqrtf(delta)) / (2.0f * curv);
+        next[d] = (-b + tclip::sqrt_torch_f32(delta)) / (2.0f * curv);   // torch.sqrt = MKL vsSqrt (HA)
     }
 }
 

@@ -1,12 +1,12 @@
 """GPU: the HIP engine (through the C ABI) against the golden vectors produced by the reference.
 
-Tolerances (north star: argmax bit-exact; alpha / responsibilities within 1e-5 relative, fp32):
-  * final argmax of u and the accuracies: exact;
-  * MM iteration counts: exact, except where the reference's own stop test sat within 2 % of its
-    1e-11 threshold (recorded in the fixture's `stop_test`): such a decision is not reproducible
-    by anything but a bit-identical trajectory, and either neighbour count is accepted;
-  * alpha: per task ||a - a_ref||_F / ||a_ref||_F <= 1e-5 (2e-5 where an MM count differs by a
-    borderline decision);  u: max |du| <= 1e-5;  v: max |dv| <= 1e-5 * max(1, |v|).
+North star: argmax bit-exact; alpha / responsibilities within 1e-5 relative (fp32).
+Measured on MI355X since the special functions are restated bit for bit (round 1): on all 14
+fixtures (K = 10..1000, zero-/few-shot, soft/hard) alpha, u and v are IDENTICAL to the reference's,
+MM iteration counts and accuracies included.  The assertions below therefore demand equality on
+the small fixtures and keep 1e-6 of slack only where full tensors are not stored; the one
+ingredient that is not restated (torch.log = MKL vsLn, closed source; the correctly rounded value
+is used, 1 ulp apart on ~1e-4 of arguments) did not hit any fixture.
 """
 import os
 
@@ -17,12 +17,7 @@ import torch
 from conftest import GOLDEN, golden_names
 
 pytestmark = pytest.mark.gpu
-# North star: 1e-5.  Measured on MI355X (round 1): <= 8.7e-6 on 9 of 10 small fixtures, 1.09e-5 on
-# zs_soft_K100_N4; the residue is torch's Sleef lgammaf_u10 differing by 1 ulp from the correctly
-# rounded value on ~20 % of arguments in [1, 2.5] (tclip_math.h).  For scale: the reference itself
-# moves by 2e-5 (zero-shot) to 1.5e-4 (few-shot) when ATen picks another CPU kernel set
-# (ATEN_CPU_CAPABILITY=default vs avx512), see DESIGN.md.
-ALPHA_TOL = 2e-5
+ALPHA_TOL = 1e-6      # large fixtures (sampled rows / checksums); measured: 0
 SMALL = [n for n in golden_names() if "K397" not in n and "K1000" not in n]
 LARGE = [n for n in golden_names() if "K397" in n or "K1000" in n]
 
@@ -66,26 +61,16 @@ def test_engine_matches_reference_golden(name):
     g = np.load(os.path.join(GOLDEN, name + ".npz"))
     few = str(g["kind"]).startswith("fs")
     res = _run(g)
-    mm = res.mm_iters.cpu().numpy()[0]
-    ref_mm = g["mm_iters"]
-    border = _borderline_iterations(g)
-    diff_it = set(np.nonzero(mm != ref_mm)[0].tolist())
-    assert diff_it <= border, f"MM iteration counts differ outside borderline decisions: {mm} vs {ref_mm}"
-    for i in diff_it:
-        assert abs(int(mm[i]) - int(ref_mm[i])) == 50
+    assert np.array_equal(res.mm_iters.cpu().numpy()[0], g["mm_iters"]), "MM iteration counts differ"
     preds = res.preds.cpu().numpy()
     assert np.array_equal(preds, g["argmax"][-1].astype(np.int32)), "final argmax differs"
-    tol = 4e-5 if diff_it else ALPHA_TOL
     fro = _fro_rel(res.alpha.cpu().numpy(), g["alpha"])
-    assert fro.max() <= tol, f"alpha Frobenius-relative error {fro.max():.2e}"
-    du = np.abs(res.u.cpu().numpy() - g["u"]).max()
-    assert du <= 1e-5, f"u max abs error {du:.2e}"
-    dv = np.abs(res.v.cpu().numpy() - g["v"]) / np.maximum(1.0, np.abs(g["v"]))
-    assert dv.max() <= 1e-5
+    assert np.array_equal(res.alpha.cpu().numpy(), g["alpha"]), f"alpha differs (Frobenius-relative {fro.max():.2e})"
+    assert np.array_equal(res.u.cpu().numpy(), g["u"]), "responsibilities differ"
+    assert np.array_equal(res.v.cpu().numpy(), g["v"]), "v differs"
     crit = res.criterions.cpu().numpy()[0]
-    # a converged alpha moves by less than its own parity tolerance per outer iteration, so the
-    # criterion inherits ALPHA_TOL as an absolute floor
-    np.testing.assert_allclose(crit, g["criterions"], rtol=(5e-2 if diff_it else 1e-3), atol=2 * ALPHA_TOL)
+    # the engine accumulates the norms in fp64, the reference in fp32
+    np.testing.assert_allclose(crit, g["criterions"], rtol=2e-6, atol=1e-9)
     y_q = torch.from_numpy(g["y_q"]).squeeze(2)
     if few:
         acc = (res.preds.cpu().long() == y_q).float().mean(1, keepdim=True).numpy()
@@ -114,7 +99,8 @@ def test_engine_matches_reference_golden_large(name):
     assert (np.abs(np.sqrt(rss.sum(-1)) / np.sqrt(g["alpha_rowsumsq"].sum(-1)) - 1.0) <= ALPHA_TOL).all()
     np.testing.assert_allclose(rs, g["alpha_rowsum"], rtol=5e-4)
     np.testing.assert_allclose(rss, g["alpha_rowsumsq"], rtol=1e-3)
-    assert np.abs(res.u.cpu().numpy() - g["u"]).max() <= 1e-5
+    assert np.array_equal(res.u.cpu().numpy(), g["u"])
+    assert np.array_equal(res.v.cpu().numpy(), g["v"])
     acc_t, _ = engine.clustering_accuracy(torch.from_numpy(g["x_q"]).cuda(), res.preds,
                                           torch.from_numpy(g["y_q"]).squeeze(2))
     assert np.array_equal(acc_t.numpy().reshape(-1, 1), g["acc"])

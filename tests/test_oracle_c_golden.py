@@ -1,7 +1,8 @@
 """CPU: the C++ oracle (oracle/tclip_oracle.cpp) against the golden vectors the reference
-produced.  It is not bit-exact (torch's lgamma/log are replaced by correctly rounded values):
-argmax and accuracies exact, MM counts exact up to borderline stop decisions, alpha within
-ALPHA_TOL in the per-task Frobenius sense."""
+produced.  Every special function and reduction order of torch CPU is restated bit for bit
+(only torch.log = MKL vsLn is replaced by the correctly rounded value, 1 ulp apart on ~1e-4 of
+arguments), and on every fixture the oracle reproduces the reference's alpha, u and v EXACTLY,
+with identical MM iteration counts and argmax traces."""
 import os
 
 import numpy as np
@@ -10,7 +11,6 @@ import pytest
 from conftest import GOLDEN, golden_names
 from oracle import c_oracle
 
-ALPHA_TOL = 2e-5       # see tests/test_gpu_parity_golden.py for the measured figures
 FAST = [n for n in golden_names() if ("K10_" in n or "K37_" in n) and not n.startswith("eval_")]
 
 
@@ -29,12 +29,9 @@ def test_c_oracle_vs_reference(name):
     K = int(g["K"])
     out = c_oracle.run(g["x_q"], g["x_s"] if few else None, g["y_s"] if few else None, iters=int(g["iters"]),
                        iter_mm=int(g["iter_mm"]), lambd=int(K / 5) * 75, hard=kind.endswith("hard"))
-    diff = set(np.nonzero(out["mm_iters"] != g["mm_iters"])[0].tolist())
-    assert diff <= _borderline(g)
+    assert np.array_equal(out["mm_iters"], g["mm_iters"])
     assert np.array_equal(out["argmax"], g["argmax"])
-    a, ref = out["alpha"].astype(np.float64), g["alpha"].astype(np.float64)
-    fro = np.sqrt(((a - ref) ** 2).sum((1, 2))) / np.sqrt((ref ** 2).sum((1, 2)))
-    assert fro.max() <= (4e-5 if diff else ALPHA_TOL)
-    assert np.abs(out["u"] - g["u"]).max() <= 1e-5
-    if not few:
-        assert np.array_equal(out["v"], g["v"])     # log + cascade sums: bit-exact
+    assert np.array_equal(out["alpha"], g["alpha"])
+    assert np.array_equal(out["u"], g["u"])
+    assert np.array_equal(out["v"], g["v"])
+    np.testing.assert_allclose(out["criterions"], g["criterions"], rtol=2e-6, atol=1e-9)   # fp64 vs fp32 norms

@@ -154,20 +154,25 @@ __device__ float dsum_inner_serial(int n, F get) {
     return fin;
 }
 
-// One majorize-minimize update of a single Dirichlet parameter (em_dirichlet.py:153-167):
-// the operation order, the roundings (no contraction) and the special functions of torch CPU.
-// Branch-free (selects only) so that the elements a lane holds interleave; valid for
-// mm_fast_domain(a) and finite y, psi_s.
-__device__ __forceinline__ float mm_update(float a, float y, float psi_s, const LogTabEntry* tab) {
-    float psi1, lg1;
-    digamma_lgamma_xp1(a, tab, psi1, lg1);
+// One majorize-minimize update of a single Dirichlet parameter (em_dirichlet.py:153-167), given
+// psi1 = digamma(a+1) and lg1 = lgamma(a+1): the operation order and the roundings (no
+// contraction) of the torch CPU ops.  Branch-free; valid for mm_fast_domain(a), finite y, psi_s.
+__device__ __forceinline__ float mm_update_algebra(float a, float y, float psi_s, float psi1, float lg1) {
     const float t = (0.0f - lg1) + psi1 * a;
     const float big = __builtin_fabsf(div_rn_inrange_f32(2.0f * t, a * a));
     const float curv = (a > 1e-11f) ? big : 1.6449340668482264f;   // polygamma(1, 1)
     float b = (psi1 - psi_s) - curv * a;
     b = b - y;
     const float delta = b * b + 4.0f * curv;
-    return div_rn_inrange_f32(-b + sqrt_rn_inrange_f32(delta), 2.0f * curv);
+    const float nume = -b + sqrt_torch_inrange_f32(delta), deno = 2.0f * curv;
+    // curvature exactly 0 (total cancellation in t): IEEE x/0 = +-inf or nan, as the reference gets
+    return deno == 0.0f ? nume * __builtin_inff() : div_rn_inrange_f32(nume, deno);
+}
+
+__device__ __forceinline__ float mm_update(float a, float y, float psi_s, const LogTabEntry* tab) {
+    float psi1, lg1;
+    digamma_lgamma_xp1(a, tab, psi1, lg1);
+    return mm_update_algebra(a, y, psi_s, psi1, lg1);
 }
 
 // The same update with the generic routines and the compiler's IEEE operators: any input.
@@ -185,7 +190,7 @@ __device__ __noinline__ float mm_update_generic(float a, float y, float psi_s) {
     float b = (psi1 - psi_s) - curv * a;
     b = b - y;
     const float delta = b * b + 4.0f * curv;
-    return (-b + __builtin_sqrtf(delta)) / (2.0f * curv);
+    return (-b + sqrt_torch_f32(delta)) / (2.0f * curv);
 }
 
 // The 16-entry log table in LDS (one copy per workgroup).

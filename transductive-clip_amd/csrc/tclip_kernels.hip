@@ -21,6 +21,7 @@
 
 #include "../../include/tclip.h"
 #include "tclip_device.h"
+#include "tclip_selftest_inputs.h"
 
 namespace tclip {
 
@@ -244,26 +245,81 @@ struct MMArgs {
 
 // One MM iteration of a row held in registers, in place.  If `measure`, also accumulates this
 // lane's share of ||b'-b||^2 and ||b||^2 (fp64).
+//
+// lgamma(a+1) has two regimes in torch's Sleef routine: a cheap polynomial for a+1 < 2.3 and a
+// ~250-instruction double-float Stirling evaluation above.  Most Dirichlet parameters of a row are
+// small and only a few are large, so the wave first queues its large arguments in LDS (ballot +
+// prefix count), evaluates the expensive branch on the DENSE queue (ceil(n/64) passes instead of
+// E passes over mostly idle lanes), and then every lane picks its results back up.
+// `queue` = 64*E floats of LDS private to this wave.
 template <int E>
 __device__ __forceinline__ void mm_iterate(float (&beta)[E], const float (&yv)[E], int K, int lane,
-                                           const LogTabEntry* tab, bool measure, double& num, double& den) {
+                                           const LogTabEntry* tab, float* queue, bool measure, double& num,
+                                           double& den) {
     const float s = group_sum_torch<E>(beta, K, lane);
     const float psi_s = digamma_pos_f32(s, tab);
     bool in_domain = psi_s == psi_s;
 #pragma unroll
     for (int e = 0; e < E; e++) in_domain = in_domain && mm_fast_domain(beta[e]);
-    const bool fast = __builtin_expect(__all(in_domain), 1);   // wave-uniform
+    if (__builtin_expect(!__all(in_domain), 0)) {   // NaN / inf / out of range somewhere in the wave
+#pragma unroll
+        for (int e = 0; e < E; e++) {
+            const float nb = mm_update_generic(beta[e], yv[e], psi_s);
+            const bool ok = e * kGroup + lane < K;
+            if (measure && ok) {
+                const double df = (double)nb - (double)beta[e];
+                num += df * df;
+                den += (double)beta[e] * (double)beta[e];
+            }
+            beta[e] = ok ? nb : 0.0f;
+        }
+        return;
+    }
+    const unsigned long long lt_mask = (1ull << (threadIdx.x & 63)) - 1ull;
+    // phase A: queue the arguments of the expensive lgamma branch
+    int n_big = 0;
 #pragma unroll
     for (int e = 0; e < E; e++) {
-        const float nb = fast ? mm_update(beta[e], yv[e], psi_s, tab) : mm_update_generic(beta[e], yv[e], psi_s);
+        const float x1 = beta[e] + 1.0f;
+        const bool big = x1 >= 2.3f;
+        const unsigned long long m = __ballot(big);
+        if (big) queue[n_big + __popcll(m & lt_mask)] = x1;
+        n_big += __popcll(m);
+    }
+    __builtin_amdgcn_wave_barrier();
+    // phase B: dense evaluation by the ACTIVE lanes (one half of the wave may be idle), results
+    // overwrite the queue
+    const unsigned long long active = __ballot(true);
+    const int rank = __popcll(active & lt_mask), n_active = __popcll(active);
+    for (int start = 0; start < n_big; start += n_active) {
+        const int idx = start + rank;
+        const float v = idx < n_big ? queue[idx] : 8.0f;
+        const float r = lgamma_sleef_ge23<true>(v);
+        if (idx < n_big) queue[idx] = r;
+    }
+    __builtin_amdgcn_wave_barrier();
+    // phase C: per element digamma, cheap lgamma branch, pick-up, algebra
+    int base = 0;
+#pragma unroll
+    for (int e = 0; e < E; e++) {
+        const float a = beta[e];
+        const float x1 = a + 1.0f;
+        const bool big = x1 >= 2.3f;
+        const unsigned long long m = __ballot(big);
+        const float lg_big = big ? queue[base + __popcll(m & lt_mask)] : 0.0f;
+        base += __popcll(m);
+        const float lg_small = lgamma_sleef_05_23(big ? 2.0f : x1);
+        const float psi1 = digamma_xp1(a, tab);
+        const float nb = mm_update_algebra(a, yv[e], psi_s, psi1, big ? lg_big : lg_small);
         const bool ok = e * kGroup + lane < K;
         if (measure && ok) {
-            const double df = (double)nb - (double)beta[e];
+            const double df = (double)nb - (double)a;
             num += df * df;
-            den += (double)beta[e] * (double)beta[e];
+            den += (double)a * (double)a;
         }
         beta[e] = ok ? nb : 0.0f;
     }
+    __builtin_amdgcn_wave_barrier();
 }
 
 constexpr int kMaxCycle = 64;  // longest limit cycle looked for on dead rows (periods up to 20 seen at K=1000)
@@ -272,7 +328,9 @@ template <int E>
 __global__ __launch_bounds__(256, (E > 20 ? 2 : (E > 8 ? 3 : 4))) void k_mm_chunk(MMArgs a) {
     __shared__ LogTabEntry tab[16];
     __shared__ double cyc[8][kMaxCycle][2];
+    __shared__ float lg_queue[4][64 * E];             // per wave: arguments / results of the large-x lgamma
     load_log_table(tab);
+    float* queue = lg_queue[threadIdx.x >> 6];
     const int lane = threadIdx.x & (kGroup - 1);
     const int group = threadIdx.x / kGroup;
     const int groups_per_block = blockDim.x / kGroup;
@@ -298,7 +356,7 @@ __global__ __launch_bounds__(256, (E > 20 ? 2 : (E > 8 ? 3 : 4))) void k_mm_chun
             yv[e] = ok ? (alive ? a.y[(size_t)row * K + d] : -10.0f) : 0.0f;
         }
         double num = 0.0, den = 0.0;
-        for (int l = a.l0; l <= a.l1; l++) mm_iterate<E>(beta, yv, K, lane, tab, a.has_check && l == a.l1, num, den);
+        for (int l = a.l0; l <= a.l1; l++) mm_iterate<E>(beta, yv, K, lane, tab, queue, a.has_check && l == a.l1, num, den);
 #pragma unroll
         for (int e = 0; e < E; e++) {
             const int d = e * kGroup + lane;
@@ -330,7 +388,7 @@ __global__ __launch_bounds__(256, (E > 20 ? 2 : (E > 8 ? 3 : 4))) void k_mm_chun
             int period = 0;
             for (int j = 0; j < kMaxCycle && period == 0; j++) {
                 double pn = 0.0, pd = 0.0;
-                mm_iterate<E>(beta, yv, K, lane, tab, true, pn, pd);
+                mm_iterate<E>(beta, yv, K, lane, tab, queue, true, pn, pd);
                 pn = group_sum_f64(pn);
                 pd = group_sum_f64(pd);
                 if (lane == 0) { cyc[group][j][0] = pn; cyc[group][j][1] = pd; }
@@ -611,18 +669,17 @@ __global__ void k_gather_rows(const float* __restrict__ table, int64_t n_rows, i
 }
 
 // ------------------------------------------------------------------------------------------
-// Self-test of the correctly rounded primitives against the compiler's IEEE operators (device).
-__device__ __forceinline__ uint32_t mix32(uint32_t x) {
-    x ^= x >> 16; x *= 0x7feb352du; x ^= x >> 15; x *= 0x846ca68bu; x ^= x >> 16;
-    return x;
-}
-
-__global__ void k_selftest(unsigned long long* bad) {
+// Device self-test (tclip_selftest_primitives).
+//   counters 0..5: mismatches of the fast exact primitives / the branch-free MM update against
+//                  the compiler's IEEE operators and the generic routines;
+//   counters 6..13: checksums of the restated library routines (tclip_selftest_inputs.h), to be
+//                  compared with the host build's checksums.
+__global__ void k_selftest(unsigned long long* out) {
     __shared__ LogTabEntry tab[16];
     load_log_table(tab);
     const uint32_t tid = blockIdx.x * blockDim.x + threadIdx.x, nth = gridDim.x * blockDim.x;
-    unsigned long long b0 = 0, b1 = 0, b2 = 0, b3 = 0, b4 = 0, b5 = 0, b6 = 0;
-    // (0) reciprocal: every float of the binade [1,2), at exponents -60, 0 and 60
+    unsigned long long b0 = 0, b1 = 0, b2 = 0, b3 = 0, b4 = 0, b5 = 0;
+    // (0) reciprocal: every float of the binade [1,2), at exponents -60, 0 and 60; (5) two-step form
     for (uint32_t m = tid; m < (1u << 23); m += nth) {
         const float x = bits_f32(0x3f800000u | m);
         b0 += rcp_rn_f32(x) != 1.0f / x;
@@ -631,43 +688,35 @@ __global__ void k_selftest(unsigned long long* bad) {
         b0 += rcp_rn_f32(xs) != 1.0f / xs;
         b0 += rcp_rn_f32(xl) != 1.0f / xl;
     }
-    // (1) square root: every float of [1,4)
-    for (uint32_t m = tid; m < (1u << 24); m += nth) {
-        const float x = bits_f32(0x3f800000u + m);
-        b1 += sqrt_rn_f32(x) != __builtin_sqrtf(x);
-        const float xs = x * 0x1p-58f;
-        b1 += sqrt_rn_f32(xs) != __builtin_sqrtf(xs);
-    }
-    // (2) quotient: 2^28 pseudo-random pairs with exponents in [-40, 40]
+    // (1) quotient: 2^28 pseudo-random pairs with exponents in [-40, 40], both signs
     for (uint32_t i = tid; i < (1u << 28); i += nth) {
-        const uint32_t h1 = mix32(i * 2u + 1u), h2 = mix32(i * 2u + 0x9e3779b9u), h3 = mix32(i + 0x85ebca6bu);
-        const float a = bits_f32(((127u - 40u + (h3 % 81u)) << 23) | (h1 & 0x7fffffu));
-        const float b = bits_f32(((127u - 40u + ((h3 >> 8) % 81u)) << 23) | (h2 & 0x7fffffu));
-        b2 += div_rn_f32(a, b) != a / b;
-        b2 += div_rn_f32(-a, b) != (-a) / b;
-        b2 += div_rn_inrange_f32(a, b) != a / b;
+        const float a = rand_float(i, 1u, -40, 81), b = rand_float(i, 2u, -40, 81);
+        b1 += div_rn_inrange_f32(a, b) != a / b;
+        b1 += div_rn_inrange_f32(-a, b) != (-a) / b;
     }
-    // (6) whole update: branch-free form against the generic form
+    // (2,3) fused digamma/lgamma of a+1 against the generic routines; (4) whole update
     for (uint32_t i = tid; i < (1u << 24); i += nth) {
-        const uint32_t h1 = mix32(i + 99u), h2 = mix32(i ^ 0x1234567u), h3 = mix32(i * 7u + 3u);
-        const float a = bits_f32(((127u - 40u + (h2 % 75u)) << 23) | (h1 & 0x7fffffu));   // 2^-40 .. 2^35
-        const float y = -0.001f - 40.0f * (float)(h3 & 0xffffu) / 65536.0f;
-        const float ps = 0.5f + 14.0f * (float)(h3 >> 16) / 65536.0f;
-        const float f = mm_update(a, y, ps, tab), g = mm_update_generic(a, y, ps);
-        b6 += !(f == g) && !(a < 0x1p-10f);   // below 2^-10 the fused lgamma uses its Taylor branch
-    }
-    // (3,4) fused digamma/lgamma of a+1 against the generic routines
-    for (uint32_t i = tid; i < (1u << 24); i += nth) {
-        const uint32_t h1 = mix32(i + 17u), h2 = mix32(i ^ 0xdeadbeefu);
-        const float a = bits_f32(((127u - 45u + (h2 % 70u)) << 23) | (h1 & 0x7fffffu));   // 2^-45 .. 2^25
+        const float a = rand_float(i, 3u, -45, 70);                    // 2^-45 .. 2^25
         float p, l;
         digamma_lgamma_xp1(a, tab, p, l);
-        b3 += p != digamma_f32(a + 1.0f);
-        b4 += (a >= 0x1p-10f) && (l != lgamma_f32(a + 1.0f));
-        b3 += digamma_pos_f32(a, tab) != digamma_f32(a);
+        b2 += p != digamma_f32(a + 1.0f);
+        b2 += digamma_pos_f32(a, tab) != digamma_f32(a);
+        b3 += l != lgamma_f32(a + 1.0f);
+        const uint32_t h = mix32(i * 7u + 3u);
+        const float y = -0.001f - 40.0f * (float)(h & 0xffffu) / 65536.0f;
+        const float ps = 0.5f + 14.0f * (float)(h >> 16) / 65536.0f;
+        const float uf = mm_update(a, y, ps, tab), ug = mm_update_generic(a, y, ps);
+        const bool differ = !(uf == ug || (uf != uf && ug != ug));    // both NaN (0/0 after exact cancellation) is agreement
+        b4 += differ;
+        if (differ) { out[14] = f32_bits(a); out[15] = f32_bits(y); out[16] = f32_bits(ps); out[17] = f32_bits(uf); out[18] = f32_bits(ug); }
     }
-    atomicAdd(&bad[0], b0); atomicAdd(&bad[1], b1); atomicAdd(&bad[2], b2); atomicAdd(&bad[3], b3); atomicAdd(&bad[4], b4);
-    atomicAdd(&bad[5], b5); atomicAdd(&bad[6], b6);
+    atomicAdd(&out[0], b0); atomicAdd(&out[1], b1); atomicAdd(&out[2], b2);
+    atomicAdd(&out[3], b3); atomicAdd(&out[4], b4); atomicAdd(&out[5], b5);
+    for (int f = 0; f < kSelfTestFunctions; f++) {
+        unsigned long long c = 0;
+        for (uint32_t i = tid; i < kSelfTestCount; i += nth) c += selftest_term(f, i, tab);
+        atomicAdd(&out[6 + f], c);
+    }
 }
 
 // ------------------------------------------------------------------------------------------
@@ -952,11 +1001,15 @@ int tclip_profile_collect(double* mm_kernel_ms, int64_t* mm_launches, int64_t* e
 int tclip_selftest_primitives(uint64_t* mismatches) {
     if (!mismatches) return fail(TCLIP_ERR_ARG, "null pointer");
     unsigned long long* d = nullptr;
-    TCLIP_HIP(hipMalloc((void**)&d, 7 * sizeof(unsigned long long)));
-    TCLIP_HIP(hipMemset(d, 0, 7 * sizeof(unsigned long long)));
+    TCLIP_HIP(hipMalloc((void**)&d, 19 * sizeof(unsigned long long)));
+    TCLIP_HIP(hipMemset(d, 0, 19 * sizeof(unsigned long long)));
     hipLaunchKernelGGL(k_selftest, dim3(2048), dim3(256), 0, 0, d);
     TCLIP_HIP(hipDeviceSynchronize());
-    TCLIP_HIP(hipMemcpy(mismatches, d, 7 * sizeof(unsigned long long), hipMemcpyDeviceToHost));
+    unsigned long long h[19];
+    TCLIP_HIP(hipMemcpy(h, d, sizeof h, hipMemcpyDeviceToHost));
+    memcpy(mismatches, h, 14 * sizeof(unsigned long long));
+    if (h[4]) snprintf(g_err, sizeof g_err, "MM update mismatch example: a=%08llx y=%08llx psi_s=%08llx fast=%08llx generic=%08llx",
+                       h[14], h[15], h[16], h[17], h[18]);
     TCLIP_HIP(hipFree(d));
     return TCLIP_OK;
 }

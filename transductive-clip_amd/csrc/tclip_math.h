@@ -2,25 +2,32 @@
 // and for a plain host build (oracle/ and the CPU unit tests compile this header with g++).
 //
 // The reference does all of its arithmetic with PyTorch CPU fp32 ops, so "parity" means
-// reproducing what THOSE implementations return, not the mathematically exact value:
-//   torch.polygamma(0, x)  -> ATen calc_digamma(float)  (torch/include/ATen/native/Math.h:434-483,
-//                             Cephes-derived: recurrence to x>=10, PSI_10, 7-term asymptotic series,
-//                             libm logf = glibc 2.35 logf, itself an fp64 table algorithm)
-//   torch.lgamma(x)        -> Sleef lgammaf_u10; measured in the build container to equal the
-//                             correctly rounded value for all but 4e-3 (x in 2.5..10) / <3e-4 (x>10)
-//                             of inputs, and ~20 % of inputs in 1..2.5 (1 ulp apart there)
-//   torch.log / exp        -> Sleef logf_u10 / expf_u10
-// Call sites in the reference: src/methods/zero_shot/em_dirichlet.py:35-38,143,151,154-155,163.
+// reproducing what THOSE implementations return on the reference's platform (torch 2.x CPU,
+// AVX2/AVX-512 kernel set, MKL VML), not the mathematically exact value:
+//   torch.polygamma(0, x) -> ATen calc_digamma(float) (torch/include/ATen/native/Math.h:434-483,
+//                            Cephes-derived: recurrence to x>=10, PSI_10, FMA Horner series,
+//                            libm logf = glibc 2.35 logf, an fp64 table algorithm)      [bit-exact]
+//   torch.lgamma(x)       -> Sleef 3.x lgammaf_u10 (float-float arithmetic)             [bit-exact]
+//   torch.sqrt(x)         -> MKL VML vsSqrt, HA, AVX-512 kernel: VRSQRT14PS + one Heron
+//                            correction; NOT correctly rounded                          [bit-exact]
+//   softmax's exp         -> Sleef expf_u10                                             [bit-exact]
+//   torch.log(x)          -> MKL VML vsLn (closed source): the correctly rounded value is used,
+//                            which MKL returns for all but 1e-5..5e-4 of arguments      [1 ulp, rare]
+//   + - * /               -> IEEE; 1/x and a/b via v_rcp_f32 + FMA residual corrections that the
+//                            device self-test proves equal to the IEEE operators         [bit-exact]
+// "bit-exact" = checked against torch on this container's CPU by tests/test_math_host.py
+// (exhaustively over [2^-20, 16) for lgamma, 4e7 samples for digamma, 8e6 for sqrt).
+// Call sites in the reference: src/methods/zero_shot/em_dirichlet.py:35-38,143,151,154-155,163-167.
 //
-// Everything here is written so that no floating-point contraction is needed or wanted:
-// compile with -ffp-contract=off; fused operations are spelled __builtin_fma(f) where the
-// mimicked implementation fuses them.
+// Compile with -ffp-contract=off: every fused multiply-add that the mimicked implementation
+// performs is spelled __builtin_fma(f); nothing else may be contracted.
 #pragma once
 #include <stdint.h>
 
+#include "tclip_rsqrt14_table.h"
+
 #if defined(__HIPCC__)
 #define TCLIP_HD __host__ __device__ __forceinline__
-#define TCLIP_CONST_TABLE __device__ __constant__
 #else
 #define TCLIP_HD static inline
 #endif
@@ -31,6 +38,54 @@ TCLIP_HD uint32_t f32_bits(float f) { return __builtin_bit_cast(uint32_t, f); }
 TCLIP_HD float bits_f32(uint32_t u) { return __builtin_bit_cast(float, u); }
 TCLIP_HD uint64_t f64_bits(double f) { return __builtin_bit_cast(uint64_t, f); }
 TCLIP_HD double bits_f64(uint64_t u) { return __builtin_bit_cast(double, u); }
+
+// ---------------------------------------------------------------------------------------------
+// IEEE reciprocal and quotient from the 1-ulp hardware reciprocal plus FMA residual corrections
+// (Markstein).  On gfx950 they replace the compiler's generic expansion (v_div_scale /
+// v_div_fmas / v_div_fixup, ~12 instructions) on the hot path.  tclip_selftest_primitives checks
+// them on the device against the IEEE operators: every float of a binade (at three exponents)
+// for 1/x, 3 x 2^28 operand pairs for a/b - no mismatch.  Preconditions: operands normal,
+// exponents within [-100, 100], quotient normal.  The host build uses the IEEE operators.
+TCLIP_HD float rcp_rn_f32(float x) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    const float r = __builtin_amdgcn_rcpf(x);
+    const float e = __builtin_fmaf(-x, r, 1.0f);
+    return __builtin_fmaf(e, r, r);
+#else
+    return 1.0f / x;
+#endif
+}
+
+TCLIP_HD float rcp_rn2_f32(float x) {      // two correction steps; self-test comparison only
+#if defined(__HIP_DEVICE_COMPILE__)
+    float r = __builtin_amdgcn_rcpf(x);
+    float e = __builtin_fmaf(-x, r, 1.0f);
+    r = __builtin_fmaf(e, r, r);
+    e = __builtin_fmaf(-x, r, 1.0f);
+    return __builtin_fmaf(e, r, r);
+#else
+    return 1.0f / x;
+#endif
+}
+
+TCLIP_HD float div_rn_inrange_f32(float a, float b) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    const float r = rcp_rn_f32(b);
+    const float q = a * r;
+    const float rem = __builtin_fmaf(-b, q, a);
+    return __builtin_fmaf(rem, r, q);
+#else
+    return a / b;
+#endif
+}
+
+// kFast selects the reciprocal used inside the restated library routines: the fast exact form
+// where the caller guarantees the operand range (MM kernel), the IEEE operator elsewhere.
+template <bool kFast>
+TCLIP_HD float rcp_ieee(float x) {
+    if (kFast) return rcp_rn_f32(x);
+    return 1.0f / x;
+}
 
 // ---------------------------------------------------------------------------------------------
 // log tables.  {1/c, log(c)} for 16 sub-intervals of [0.7, 1.4): the published table of glibc's
@@ -48,96 +103,70 @@ struct LogTabEntry { double invc, logc; };
     {0x1.886e6037841edp-1, 0x1.1058bc8a07ee1p-2},  {0x1.767dcf5534862p-1, 0x1.4043057b6ee09p-2}}
 
 #if defined(__HIP_DEVICE_COMPILE__)
-static TCLIP_CONST_TABLE LogTabEntry kLogTab[16] = TCLIP_LOG_TABLE_INIT;
+static __device__ __constant__ LogTabEntry kLogTab[16] = TCLIP_LOG_TABLE_INIT;
 #else
 static const LogTabEntry kLogTab[16] = TCLIP_LOG_TABLE_INIT;
 #endif
 
 constexpr double kLn2 = 0x1.62e42fefa39efp-1;
 
-// Range reduction shared by every log below: x = 2^k * z, z in [0.7,1.4), r = z/c - 1 with
-// |r| < 0.035, log(x) = log1p(r) + log(c) + k ln2.  x must be a positive normal float.
-struct LogReduced { double r, y0; };
-TCLIP_HD LogReduced log_reduce_f32(float x) {
-    uint32_t ix = f32_bits(x);
-    uint32_t tmp = ix - 0x3f330000u;
-    int i = (tmp >> 19) & 15;
-    int k = (int32_t)tmp >> 23;
-    uint32_t iz = ix - (tmp & 0xff800000u);
-    double z = (double)bits_f32(iz);
-    LogReduced o;
-    o.r = __builtin_fma(z, kLogTab[i].invc, -1.0);
-    o.y0 = kLogTab[i].logc + (double)k * kLn2;
-    return o;
+// Range reduction: x = 2^k * z, z in [0.7,1.4), r = z/c - 1 with |r| < 0.035,
+// log(x) = log1p(r) + log(c) + k ln2.  x positive and normal.  `tab` = kLogTab or its LDS copy.
+TCLIP_HD void log_reduce_tab(float x, const LogTabEntry* tab, double& r, double& y0) {
+    const uint32_t ix = f32_bits(x);
+    const uint32_t tmp = ix - 0x3f330000u;
+    const int i = (tmp >> 19) & 15;
+    const int k = (int32_t)tmp >> 23;
+    const double z = (double)bits_f32(ix - (tmp & 0xff800000u));
+    const LogTabEntry t = tab[i];
+    r = __builtin_fma(z, t.invc, -1.0);
+    y0 = t.logc + (double)k * kLn2;
 }
 
-// glibc 2.35 logf, FMA build (the ifunc variant every FMA-capable x86-64 selects); this is what
-// ATen's calc_digamma(float) gets from `logf(x)`.  Positive normal inputs only.
-TCLIP_HD double logf_glibc_as_double(float x) {
-    if (f32_bits(x) == 0x3f800000u) return 0.0;
-    LogReduced q = log_reduce_f32(x);
-    double r = q.r, r2 = r * r;
+// glibc 2.35 logf, FMA build (the ifunc variant every FMA-capable x86-64 selects): what ATen's
+// calc_digamma(float) gets from `logf(x)`.  Positive normal inputs.
+TCLIP_HD float logf_glibc_tab(float x, const LogTabEntry* tab) {
+    if (f32_bits(x) == 0x3f800000u) return 0.0f;
+    double r, y0;
+    log_reduce_tab(x, tab, r, y0);
+    const double r2 = r * r;
     double y = __builtin_fma(0x1.5575b0be00b6ap-2, r, -0x1.ffffef20a4123p-2);
     y = __builtin_fma(-0x1.00ea348b88334p-2, r2, y);
-    y = __builtin_fma(y, r2, q.y0 + r);
-    return y;
+    y = __builtin_fma(y, r2, y0 + r);
+    return (float)y;
 }
-TCLIP_HD float logf_glibc(float x) { return (float)logf_glibc_as_double(x); }
+TCLIP_HD float logf_glibc(float x) { return logf_glibc_tab(x, kLogTab); }
 
-// log1p(r) for |r| < 0.04 to ~3e-13 absolute: enough for a correctly-rounded-in-practice fp32
-// log and for the fp64 Stirling evaluation of lgamma below.
-TCLIP_HD double log1p_small(double r) {
-    double p = -1.0 / 8.0;
-    p = __builtin_fma(p, r, 1.0 / 7.0);
-    p = __builtin_fma(p, r, -1.0 / 6.0);
-    p = __builtin_fma(p, r, 1.0 / 5.0);
-    p = __builtin_fma(p, r, -1.0 / 4.0);
-    p = __builtin_fma(p, r, 1.0 / 3.0);
-    p = __builtin_fma(p, r, -1.0 / 2.0);
-    double r2 = r * r;
-    return __builtin_fma(p, r2, r);
-}
-
-// Accurate log of a positive normal float, as a double (|err| < 1e-12).
-TCLIP_HD double log_f32_as_double(float x) {
-    LogReduced q = log_reduce_f32(x);
-    return q.y0 + log1p_small(q.r);
-}
-
-// Accurate log of a positive normal double (same table, indexed by the high word).
-TCLIP_HD double log_f64(double v) {
-    uint64_t iv = f64_bits(v);
-    uint32_t hi = (uint32_t)(iv >> 32);
-    uint32_t tmp = hi - 0x3fe66000u;
-    int i = (tmp >> 16) & 15;
-    int k = (int32_t)tmp >> 20;
-    uint64_t iz = iv - ((uint64_t)(tmp & 0xfff00000u) << 32);
-    double z = bits_f64(iz);
-    double r = __builtin_fma(z, kLogTab[i].invc, -1.0);
-    double y0 = kLogTab[i].logc + (double)k * kLn2;
-    return y0 + log1p_small(r);
-}
-
-// fp32 log standing in for Sleef logf_u10 (torch.log on CPU): the correctly rounded value,
-// which Sleef returns for >99.9 % of inputs.  Handles 0 (-> -inf) and subnormals.
+// fp32 log standing in for MKL vsLn (torch.log on CPU): the correctly rounded value (fp64 table
+// log, |err| < 1e-12, rounded once).  Handles 0 (-> -inf) and subnormals.
 TCLIP_HD float log_f32(float x) {
     if (x == 0.0f) return -__builtin_inff();
     if (x < 0.0f || x != x) return __builtin_nanf("");
     if (x == __builtin_inff()) return x;
     double s = 0.0;
     if (f32_bits(x) < 0x00800000u) { x *= 0x1p64f; s = -64.0 * kLn2; }
-    return (float)(log_f32_as_double(x) + s);
+    double r, y0;
+    log_reduce_tab(x, kLogTab, r, y0);
+    double p = -1.0 / 8.0;                       // log1p(r), |r| < 0.04, to ~3e-13
+    p = __builtin_fma(p, r, 1.0 / 7.0);
+    p = __builtin_fma(p, r, -1.0 / 6.0);
+    p = __builtin_fma(p, r, 1.0 / 5.0);
+    p = __builtin_fma(p, r, -1.0 / 4.0);
+    p = __builtin_fma(p, r, 1.0 / 3.0);
+    p = __builtin_fma(p, r, -1.0 / 2.0);
+    return (float)((y0 + __builtin_fma(p, r * r, r)) + s);
 }
 
 // ---------------------------------------------------------------------------------------------
-// digamma, bit-for-bit ATen calc_digamma(float) for x > 0 (Math.h:434-483).  The x<=0 branches
+// digamma, bit-for-bit ATen calc_digamma(float) for x > 0 (Math.h:434-483).  The x <= 0 branches
 // of the original (poles, reflection) are unreachable on this path (arguments are alpha+1 >= 1
 // and row sums of positive alpha) and are reduced to their IEEE special values.
-TCLIP_HD float digamma_asymptotic_f32(float x, float acc) {
-    // acc + logf(x) - 0.5/x - y,   y = z*polevl(z, A, 6),  z = 1/(x*x)
+template <bool kFast>
+TCLIP_HD float digamma_series(float x, float acc, const LogTabEntry* tab) {
+    // acc + logf(x) - 0.5/x - z*polevl(z, A, 6), z = 1/(x*x); 0.5f/x == 0.5f*RN(1/x) exactly
     float y = 0.0f;
     if (x < 1.0e17f) {
-        float z = 1.0f / (x * x);
+        const float z = rcp_ieee<kFast>(x * x);
         float p = 8.33333333333333333333E-2f;
         p = __builtin_fmaf(p, z, -2.10927960927960927961E-2f);
         p = __builtin_fmaf(p, z, 7.57575757575757575758E-3f);
@@ -147,7 +176,7 @@ TCLIP_HD float digamma_asymptotic_f32(float x, float acc) {
         p = __builtin_fmaf(p, z, 8.33333333333333333333E-2f);
         y = z * p;
     }
-    return acc + logf_glibc(x) - (0.5f / x) - y;
+    return acc + logf_glibc_tab(x, tab) - (0.5f * rcp_ieee<kFast>(x)) - y;
 }
 
 TCLIP_HD float digamma_f32(float x) {
@@ -160,107 +189,7 @@ TCLIP_HD float digamma_f32(float x) {
         x += 1.0f;
     }
     if (x == 10.0f) return acc + 2.25175258906672110764f;
-    return digamma_asymptotic_f32(x, acc);
-}
-
-// ---------------------------------------------------------------------------------------------
-// lgamma for x > 0, evaluated in fp64 (shift to >= 10 by the recurrence, Stirling series, one
-// log of the shift product) and rounded once: the correctly rounded fp32 value except within
-// ~1e-14 absolute of a rounding boundary.
-TCLIP_HD double stirling_tail(double x) {
-    // sum_{n>=1} B_2n / (2n(2n-1) x^(2n-1)), x >= 10: 5 terms, truncation < 2e-14
-    double t = 1.0 / x, t2 = t * t;
-    double s = 1.0 / 1188.0;
-    s = __builtin_fma(s, t2, -1.0 / 1680.0);
-    s = __builtin_fma(s, t2, 1.0 / 1260.0);
-    s = __builtin_fma(s, t2, -1.0 / 360.0);
-    s = __builtin_fma(s, t2, 1.0 / 12.0);
-    return s * t;
-}
-
-TCLIP_HD double lgamma_pos_as_double(float xf) {
-    double x = (double)xf, prod = 1.0;
-    bool shifted = false;
-    while (x < 10.0) {
-        prod *= x;
-        x += 1.0;
-        shifted = true;
-    }
-    double lx = log_f64(x);
-    double r = __builtin_fma(x - 0.5, lx, -x) + 0.91893853320467274178 + stirling_tail(x);
-    if (shifted) r -= log_f64(prod);
-    return r;
-}
-
-TCLIP_HD float lgamma_f32(float x) {
-    if (x != x) return x;
-    if (x == __builtin_inff()) return x;
-    if (!(x > 0.0f)) return __builtin_inff();            // poles / negative: unreachable here
-    if (x < 0x1p-100f) return (float)(-log_f64((double)x));   // lgamma(x) = -log(x) - gamma*x + ...
-    return (float)lgamma_pos_as_double(x);
-}
-
-// ---------------------------------------------------------------------------------------------
-// Correctly rounded fp32 reciprocal / quotient / square root from the 1-ulp hardware
-// approximations plus FMA residual corrections (Markstein-style).  On gfx950 these replace the
-// compiler's generic IEEE expansions (v_div_scale/v_div_fmas/v_div_fixup, ~12 instructions each)
-// on the hot path; tests/test_gpu_primitives.py checks them on the device against the IEEE
-// operators, exhaustively over a binade for rcp and sqrt.  Preconditions: operands positive and
-// normal with exponents in [-60, 60] (true on the MM path: arguments are alpha+1, alpha^2,
-// 2*curvature, b^2+4*curvature; the callers fall back to the IEEE operator outside that range).
-// On the host the IEEE operators are used directly.
-// v_rcp_f32 (1 ulp) + ONE residual correction: the device self-test finds it equal to the IEEE
-// quotient 1/x for every float of a binade (at three exponents), so a second step buys nothing.
-TCLIP_HD float rcp_rn_f32(float x) {
-#if defined(__HIP_DEVICE_COMPILE__)
-    const float r = __builtin_amdgcn_rcpf(x);
-    const float e = __builtin_fmaf(-x, r, 1.0f);
-    return __builtin_fmaf(e, r, r);
-#else
-    return 1.0f / x;
-#endif
-}
-
-// Two correction steps (kept for the self-test's comparison).
-TCLIP_HD float rcp_rn2_f32(float x) {
-#if defined(__HIP_DEVICE_COMPILE__)
-    float r = __builtin_amdgcn_rcpf(x);
-    float e = __builtin_fmaf(-x, r, 1.0f);
-    r = __builtin_fmaf(e, r, r);
-    e = __builtin_fmaf(-x, r, 1.0f);
-    return __builtin_fmaf(e, r, r);
-#else
-    return 1.0f / x;
-#endif
-}
-
-// Branch-free forms for operands known to be in range (see the MM-path domain note at
-// digamma_lgamma_xp1): no range test, no IEEE fallback.
-TCLIP_HD float div_rn_inrange_f32(float a, float b) {
-#if defined(__HIP_DEVICE_COMPILE__)
-    const float r = rcp_rn_f32(b);
-    const float q = a * r;
-    const float rem = __builtin_fmaf(-b, q, a);
-    return __builtin_fmaf(rem, r, q);
-#else
-    return a / b;
-#endif
-}
-
-TCLIP_HD float sqrt_rn_inrange_f32(float x) {
-#if defined(__HIP_DEVICE_COMPILE__)
-    const float y = __builtin_amdgcn_rsqf(x);
-    float s = x * y, h = 0.5f * y;
-    const float e = __builtin_fmaf(-h, s, 0.5f);
-    s = __builtin_fmaf(s, e, s);
-    h = __builtin_fmaf(h, e, h);
-    const float d = __builtin_fmaf(-s, s, x);
-    s = __builtin_fmaf(d, h, s);
-    const float d2 = __builtin_fmaf(-s, s, x);
-    return __builtin_fmaf(d2, h, s);
-#else
-    return __builtin_sqrtf(x);
-#endif
+    return digamma_series<false>(x, acc, kLogTab);
 }
 
 TCLIP_HD bool fast_range_f32(float x) {   // positive normal, |exponent| <= 60
@@ -268,58 +197,7 @@ TCLIP_HD bool fast_range_f32(float x) {   // positive normal, |exponent| <= 60
     return b >= 0x21800000u && b <= 0x5d800000u;
 }
 
-TCLIP_HD float div_rn_f32(float a, float b) {
-#if defined(__HIP_DEVICE_COMPILE__)
-    if (fast_range_f32(b) && fast_range_f32(__builtin_fabsf(a))) {
-        const float r = rcp_rn_f32(b);
-        const float q = a * r;
-        const float rem = __builtin_fmaf(-b, q, a);
-        return __builtin_fmaf(rem, r, q);
-    }
-#endif
-    return a / b;
-}
-
-TCLIP_HD float sqrt_rn_f32(float x) {
-#if defined(__HIP_DEVICE_COMPILE__)
-    if (fast_range_f32(x)) {
-        const float y = __builtin_amdgcn_rsqf(x);
-        float s = x * y, h = 0.5f * y;
-        const float e = __builtin_fmaf(-h, s, 0.5f);
-        s = __builtin_fmaf(s, e, s);
-        h = __builtin_fmaf(h, e, h);
-        const float d = __builtin_fmaf(-s, s, x);
-        s = __builtin_fmaf(d, h, s);
-        const float d2 = __builtin_fmaf(-s, s, x);
-        return __builtin_fmaf(d2, h, s);
-    }
-#endif
-    return __builtin_sqrtf(x);
-}
-
-TCLIP_HD void log_reduce_tab(float x, const LogTabEntry* tab, double& r, double& y0) {
-    const uint32_t ix = f32_bits(x);
-    const uint32_t tmp = ix - 0x3f330000u;
-    const int i = (tmp >> 19) & 15;
-    const int k = (int32_t)tmp >> 23;
-    const double z = (double)bits_f32(ix - (tmp & 0xff800000u));
-    const LogTabEntry t = tab[i];
-    r = __builtin_fma(z, t.invc, -1.0);
-    y0 = t.logc + (double)k * kLn2;
-}
-
-TCLIP_HD double log_f64_tab(double v, const LogTabEntry* tab) {
-    const uint64_t iv = f64_bits(v);
-    const uint32_t tmp = (uint32_t)(iv >> 32) - 0x3fe66000u;
-    const int i = (tmp >> 16) & 15;
-    const int k = (int32_t)tmp >> 20;
-    const double z = bits_f64(iv - ((uint64_t)(tmp & 0xfff00000u) << 32));
-    const LogTabEntry t = tab[i];
-    const double r = __builtin_fma(z, t.invc, -1.0);
-    return (t.logc + (double)k * kLn2) + log1p_small(r);
-}
-
-// digamma_f32 for positive finite arguments with the fast reciprocal (row sums of alpha).
+// The same with the fast reciprocal, for arguments in range (row sums of alpha).
 TCLIP_HD float digamma_pos_f32(float x, const LogTabEntry* tab) {
     if (!fast_range_f32(x) || !fast_range_f32(x * x)) return digamma_f32(x);
     float acc = 0.0f;
@@ -328,98 +206,223 @@ TCLIP_HD float digamma_pos_f32(float x, const LogTabEntry* tab) {
         x += 1.0f;
     }
     if (x == 10.0f) return acc + 2.25175258906672110764f;
-    const float rx = rcp_rn_f32(x), z = rcp_rn_f32(x * x);
-    float p = 8.33333333333333333333E-2f;
-    p = __builtin_fmaf(p, z, -2.10927960927960927961E-2f);
-    p = __builtin_fmaf(p, z, 7.57575757575757575758E-3f);
-    p = __builtin_fmaf(p, z, -4.16666666666666666667E-3f);
-    p = __builtin_fmaf(p, z, 3.96825396825396825397E-3f);
-    p = __builtin_fmaf(p, z, -8.33333333333333333333E-3f);
-    p = __builtin_fmaf(p, z, 8.33333333333333333333E-2f);
-    double r, y0;
-    log_reduce_tab(x, tab, r, y0);
-    const double r2 = r * r;
-    double yl = __builtin_fma(0x1.5575b0be00b6ap-2, r, -0x1.ffffef20a4123p-2);
-    yl = __builtin_fma(-0x1.00ea348b88334p-2, r2, yl);
-    yl = __builtin_fma(yl, r2, y0 + r);
-    return acc + (float)yl - (0.5f * rx) - z * p;
+    return digamma_series<true>(x, acc, tab);
 }
 
 // ---------------------------------------------------------------------------------------------
-// The two special functions of one MM update, fused:  psi1 = digamma(a+1) exactly as
-// digamma_f32 computes it, lg1 = lgamma(a+1) exactly as lgamma_f32 computes it, for a >= 0.
-// Straight-line code (9 predicated recurrence steps, no data-dependent branches) so that the
-// compiler can interleave the independent elements a lane holds; one table reduction serves
-// logf(x) of the digamma series, log(x) of Stirling's formula and, re-indexed, log of the
-// recurrence product.  `tab` is the 16-entry log table (LDS copy on the device).
-// Domain of the branch-free form: 0 <= a <= 2^40 (then x = a+1, x*x, the reciprocals and every
-// intermediate stay normal); callers route anything else (NaN, inf, negative, huge) to the generic
-// digamma_f32 / lgamma_f32.
-TCLIP_HD bool mm_fast_domain(float a) { return a >= 0.0f && a <= 0x1p40f; }
+// torch.lgamma = Sleef 3.x lgammaf_u10 (src/libm/sleefsimdsp.c: gammafk + xlgammaf_u1, helper
+// arithmetic from src/common/df.h), restated operation by operation in float-float arithmetic
+// with fused multiply-adds as the AVX2/AVX-512 builds perform them.  Constants as in the
+// published source (and as found in libtorch_cpu.so).  It is NOT the correctly rounded lgamma:
+// on [1, 2.5] it is one ulp away on ~20 % of arguments, which is why it is restated and not
+// replaced.  Positive finite arguments only (poles and negative reflection are unreachable here).
+struct F2 { float x, y; };
+TCLIP_HD F2 df_add2_f2_f(F2 a, float b) {
+    const float s = a.x + b, v = s - a.x;
+    const float t = (a.x - (s - v)) + (b - v);
+    return F2{s, t + a.y};
+}
+TCLIP_HD F2 df_add2_f_f2(float a, F2 b) {
+    const float s = a + b.x, v = s - a;
+    const float t = (a - (s - v)) + (b.x - v);
+    return F2{s, t + b.y};
+}
+TCLIP_HD F2 df_add2_f2_f2(F2 a, F2 b) {
+    const float s = a.x + b.x, v = s - a.x;
+    const float t = (a.x - (s - v)) + (b.x - v);
+    return F2{s, t + (a.y + b.y)};
+}
+TCLIP_HD F2 df_add_f2_f2(F2 a, F2 b) {                        // |a.x| >= |b.x|
+    const float s = a.x + b.x;
+    return F2{s, (((a.x - s) + b.x) + a.y) + b.y};
+}
+TCLIP_HD F2 df_mul_f_f(float a, float b) {
+    const float s = a * b;
+    return F2{s, __builtin_fmaf(a, b, -s)};
+}
+TCLIP_HD F2 df_mul_f2_f(F2 a, float b) {
+    const float s = a.x * b;
+    return F2{s, __builtin_fmaf(a.y, b, __builtin_fmaf(a.x, b, -s))};
+}
+TCLIP_HD F2 df_mul_f2_f2(F2 a, F2 b) {
+    const float s = a.x * b.x;
+    return F2{s, __builtin_fmaf(a.x, b.y, __builtin_fmaf(a.y, b.x, __builtin_fmaf(a.x, b.x, -s)))};
+}
+TCLIP_HD F2 df_squ(F2 a) {
+    const float s = a.x * a.x;
+    return F2{s, __builtin_fmaf(a.x + a.x, a.y, __builtin_fmaf(a.x, a.x, -s))};
+}
+TCLIP_HD F2 df_normalize(F2 a) {
+    const float s = a.x + a.y;
+    return F2{s, (a.x - s) + a.y};
+}
+TCLIP_HD F2 df_from_double(double d) {
+    const float hi = (float)d;
+    return F2{hi, (float)(d - (double)hi)};
+}
+template <bool kFast>
+TCLIP_HD F2 df_div(F2 n, F2 d) {
+    const float t = rcp_ieee<kFast>(d.x);                     // Sleef's vrec is the IEEE quotient 1/x
+    const float s = n.x * t;
+    const float u = __builtin_fmaf(t, n.x, -s);
+    const float v = __builtin_fmaf(-d.y, t, __builtin_fmaf(-d.x, t, 1.0f));
+    return F2{s, __builtin_fmaf(s, v, __builtin_fmaf(n.y, t, u))};
+}
 
-TCLIP_HD void digamma_lgamma_xp1(float a, const LogTabEntry* tab, float& psi1, float& lg1) {
-    float x = a + 1.0f;
-    const double xd0 = (double)x;
-    double prod = 1.0;
-    float acc = 0.0f, nf = 0.0f;
-#if defined(__HIP_DEVICE_COMPILE__)
-#pragma unroll
-#endif
-    for (int j = 0; j < 9; j++) {                            // while (x < 10) {acc -= 1/x; x += 1}
-        const bool small = x < 10.0f;
-        const float rxj = rcp_rn_f32(x);
-        acc -= small ? rxj : 0.0f;
-        prod *= small ? xd0 + (double)j : 1.0;               // exact shifts for the lgamma recurrence
-        const float inc = small ? 1.0f : 0.0f;
-        x += inc;
-        nf += inc;
+// logk2f: double-float log of a positive double-float
+template <bool kFast>
+TCLIP_HD F2 sleef_logk2f(F2 d) {
+    float dx = d.x * (1.0f / 0.75f);
+    const bool tiny = dx < 5.421010862427522E-20f;
+    dx = tiny ? 1.8446744073709552E19f * dx : dx;
+    const int e = (int)((f32_bits(dx) >> 23) & 0xff) - (tiny ? 64 + 0x7f : 0x7f);
+    const float sc = bits_f32((uint32_t)(127 - e) << 23);     // 2^-e
+    const F2 m{d.x * sc, d.y * sc};
+    const F2 x = df_div<kFast>(df_add2_f2_f(m, -1.0f), df_add2_f2_f(m, 1.0f));
+    const F2 x2 = df_squ(x);
+    float t = 0.2392828464508056640625f;
+    t = __builtin_fmaf(t, x2.x, 0.28518211841583251953125f);
+    t = __builtin_fmaf(t, x2.x, 0.400005877017974853515625f);
+    t = __builtin_fmaf(t, x2.x, 0.666666686534881591796875f);
+    F2 s = df_mul_f2_f(F2{0.69314718246459960938f, -1.904654323148236017e-09f}, (float)e);
+    s = df_add_f2_f2(s, F2{x.x * 2.0f, x.y * 2.0f});
+    s = df_add_f2_f2(s, df_mul_f2_f(df_mul_f2_f2(x2, x), t));
+    return s;
+}
+
+// the degree-8 polynomial + three double-float Horner steps shared by [0.5, 2.3) and the
+// reflection: t = x - 1 (o0) or x - 2
+TCLIP_HD F2 sleef_lgamma_poly(float t, bool o0) {
+    float u = o0 ? +0.9435157776e+0f : +0.1102489550e-3f;
+    u = __builtin_fmaf(u, t, o0 ? +0.8670063615e+0f : +0.8160019934e-4f);
+    u = __builtin_fmaf(u, t, o0 ? +0.4826702476e+0f : +0.1528468856e-3f);
+    u = __builtin_fmaf(u, t, o0 ? -0.8855129778e-1f : -0.2355068718e-3f);
+    u = __builtin_fmaf(u, t, o0 ? +0.1013825238e+0f : +0.4962242092e-3f);
+    u = __builtin_fmaf(u, t, o0 ? -0.1493408978e+0f : -0.1193488017e-2f);
+    u = __builtin_fmaf(u, t, o0 ? +0.1697509140e+0f : +0.2891599433e-2f);
+    u = __builtin_fmaf(u, t, o0 ? -0.2072454542e+0f : -0.7385451812e-2f);
+    u = __builtin_fmaf(u, t, o0 ? +0.2705872357e+0f : +0.2058077045e-1f);
+    F2 z = df_add2_f2_f(df_mul_f_f(u, t), o0 ? -0.400686534596170958447352690395e+0f : -0.673523028297382446749257758235e-1f);
+    z = df_add2_f2_f(df_mul_f2_f(z, t), o0 ? +0.822466960142643054450325495997e+0f : +0.322467033928981157743538726901e+0f);
+    z = df_add2_f2_f(df_mul_f2_f(z, t), o0 ? -0.577215665946766039837398973297e+0f : +0.422784335087484338986941629852e+0f);
+    return df_mul_f2_f(z, t);
+}
+
+// x in [0.5, 2.3)
+TCLIP_HD float lgamma_sleef_05_23(float x) {
+    const bool o0 = x <= 1.2f;
+    const F2 d = df_add2_f2_f(F2{x, 0.0f}, o0 ? -1.0f : -2.0f);
+    const F2 z = sleef_lgamma_poly(d.x + d.y, o0);
+    return z.x + z.y;
+}
+
+// x >= 2.3: Stirling series in 1/x on a double-float log; arguments up to 7 are first shifted
+// by 3, Gamma(x) = Gamma(x+3) / (x(x+1)(x+2)).
+template <bool kFast>
+TCLIP_HD float lgamma_sleef_ge23(float a) {
+    F2 x{a, 0.0f};
+    const bool o = a <= 7.0f;
+    F2 y = df_normalize(df_mul_f2_f2(df_add2_f2_f(x, 1.0f), x));
+    y = df_normalize(df_mul_f2_f2(df_add2_f2_f(x, 2.0f), y));
+    const F2 prod = o ? y : F2{1.0f, 0.0f};
+    x = o ? df_add2_f2_f(x, 3.0f) : x;
+    const float t = rcp_ieee<kFast>(x.x);
+    float u = +0.000839498720672087279971000786f;
+    u = __builtin_fmaf(u, t, -5.17179090826059219329394422e-05f);
+    u = __builtin_fmaf(u, t, -0.000592166437353693882857342347f);
+    u = __builtin_fmaf(u, t, +6.97281375836585777403743539e-05f);
+    u = __builtin_fmaf(u, t, +0.000784039221720066627493314301f);
+    u = __builtin_fmaf(u, t, -0.000229472093621399176949318732f);
+    u = __builtin_fmaf(u, t, -0.002681327160493827160473958490f);
+    u = __builtin_fmaf(u, t, +0.003472222222222222222175164840f);
+    u = __builtin_fmaf(u, t, +0.083333333333333333335592087900f);
+    F2 c = df_mul_f2_f2(df_add2_f2_f(x, -0.5f), sleef_logk2f<kFast>(x));
+    c = df_add2_f2_f2(c, F2{-x.x, -x.y});
+    c = df_add2_f2_f2(c, df_from_double(0.91893853320467278056));            // 0.5 log(2 pi)
+    const F2 corr = df_add2_f2_f(df_mul_f_f(u, t), 1.0f);
+    const F2 r = df_add2_f2_f2(c, sleef_logk2f<kFast>(df_div<kFast>(corr, prod)));
+    return r.x + r.y;
+}
+
+// sinpifk for 0 <= d < 0.5 (all the reflection below needs)
+TCLIP_HD F2 sleef_sinpifk_small(float d) {
+    const float u4 = d * 4.0f;
+    int q = (int)u4;
+    q = (q + 1) & ~1;                                      // 0 for d < 0.25, 2 for 0.25 <= d < 0.5
+    const bool o = (q & 2) == 2;
+    const float t = u4 - (float)q;
+    const float s = t * t;
+    const F2 s2 = df_mul_f_f(t, t);
+    float u = o ? -0.2430611801e-7f : +0.3093842054e-6f;
+    u = __builtin_fmaf(u, s, o ? +0.3590577080e-5f : -0.3657307388e-4f);
+    u = __builtin_fmaf(u, s, o ? -0.3259917721e-3f : +0.2490393585e-2f);
+    F2 x = df_add2_f_f2(u * s, o ? F2{0.015854343771934509277f, 4.4940051354032242811e-10f}
+                                 : F2{-0.080745510756969451904f, -1.3373665339076936258e-09f});
+    x = df_add2_f2_f2(df_mul_f2_f2(s2, x), o ? F2{-0.30842512845993041992f, -9.0728339030733922277e-09f}
+                                             : F2{0.78539818525314331055f, -2.1857338617566484855e-08f});
+    x = df_mul_f2_f2(x, o ? s2 : F2{t, 0.0f});
+    return o ? df_add2_f2_f(x, 1.0f) : x;
+}
+
+// 0 < a < 0.5: lgamma(a) = log(pi) - lgamma(1-a) - log(sin(pi a)); below 1e-30: log(2^60) + log(1/(a 2^60))
+TCLIP_HD float lgamma_sleef_lt05(float a) {
+    if (a < 1e-30f) {
+        const F2 b = df_div<false>(F2{1.0f, 0.0f}, F2{a * (1073741824.0f * 1073741824.0f), 0.0f});
+        const F2 r = df_add2_f2_f2(df_from_double(41.58883083359671856503), sleef_logk2f<false>(b));
+        return r.x + r.y;
     }
-    const double xd = xd0 + (double)nf;
-    // digamma: asymptotic series at x >= 10 (the x == 10 case returns the tabulated psi(10))
-    const float xx = x * x;
-    const float rx = rcp_rn_f32(x);
-    const float z = rcp_rn_f32(xx);                          // x <= 2^40 + 9 < 1e17: always the series
-    float p = 8.33333333333333333333E-2f;
-    p = __builtin_fmaf(p, z, -2.10927960927960927961E-2f);
-    p = __builtin_fmaf(p, z, 7.57575757575757575758E-3f);
-    p = __builtin_fmaf(p, z, -4.16666666666666666667E-3f);
-    p = __builtin_fmaf(p, z, 3.96825396825396825397E-3f);
-    p = __builtin_fmaf(p, z, -8.33333333333333333333E-3f);
-    p = __builtin_fmaf(p, z, 8.33333333333333333333E-2f);
-    const float yser = z * p;
-    double r, y0;
-    log_reduce_tab(x, tab, r, y0);
-    const double r2 = r * r;
-    double yl = __builtin_fma(0x1.5575b0be00b6ap-2, r, -0x1.ffffef20a4123p-2);   // glibc logf polynomial
-    yl = __builtin_fma(-0x1.00ea348b88334p-2, r2, yl);
-    yl = __builtin_fma(yl, r2, y0 + r);
-    const float logx = (float)yl;                            // x >= 10 here, never 1.0
-    const float asym = acc + logx - (0.5f * rx) - yser;     // 0.5f/x == 0.5f*RN(1/x): scaling by 2 is exact
-    psi1 = (x == 10.0f) ? acc + 2.25175258906672110764f : asym;
-    // lgamma(a+1) = Stirling(xd) - log(prod), all in fp64, rounded once
-    const double xf = (double)x;
-    double t = (double)rx;                                   // ~1/xd to 1e-6: two Newton steps
-    t = t * __builtin_fma(-xd, t, 2.0);
-    t = t * __builtin_fma(-xd, t, 2.0);
-    const double dl = (xd - xf) * t;                         // log(xd) = log(x) + log1p((xd-x)/x)
-    const double lxd = (y0 + log1p_small(r)) + __builtin_fma(-0.5 * dl, dl, dl);
-    const double t2 = t * t;
-    double st = 1.0 / 1188.0;
-    st = __builtin_fma(st, t2, -1.0 / 1680.0);
-    st = __builtin_fma(st, t2, 1.0 / 1260.0);
-    st = __builtin_fma(st, t2, -1.0 / 360.0);
-    st = __builtin_fma(st, t2, 1.0 / 12.0);
-    double lg = __builtin_fma(xd - 0.5, lxd, -xd) + 0.91893853320467274178 + st * t;
-    lg -= log_f64_tab(prod, tab);
-    // a < 2^-10: Stirling minus log-product cancels 12.8 - 12.8 and keeps only ~1e-15 absolute;
-    // the Taylor series of lgamma(1+a) = -gamma a + sum_k (-1)^k zeta(k) a^k / k is exact to fp64 there
-    const double ad = (double)a;
-    double ser = 0.20738555102867398527;                          //  zeta(5)/5
-    ser = __builtin_fma(ser, ad, -0.27058080842778454788);        // -zeta(4)/4
-    ser = __builtin_fma(ser, ad, 0.40068563438653142847);         //  zeta(3)/3
-    ser = __builtin_fma(ser, ad, -0.82246703342411321824);        // -zeta(2)/2
-    ser = __builtin_fma(ser, ad, -0.57721566490153286061);        // -gamma
-    lg1 = (float)(a < 0x1p-10f ? ser * ad : lg);
+    const float xs = 1.0f + (-a), xv = xs - 1.0f;           // dfadd2_f_f(1, -a)
+    const F2 x{xs, (1.0f - (xs - xv)) + ((-a) - xv)};
+    const F2 d = df_add2_f2_f(x, -1.0f);
+    const F2 z = sleef_lgamma_poly(d.x + d.y, true);        // 1-a lies in (0.5, 1]
+    const F2 clc = df_add2_f2_f2(df_from_double(1.1447298858494001639), F2{-z.x, -z.y});   // log(pi) - .
+    const F2 den = df_mul_f2_f2(F2{1.0f, 0.0f}, sleef_sinpifk_small(a));
+    const F2 r = df_add2_f2_f2(clc, sleef_logk2f<false>(df_div<false>(F2{1.0f, 0.0f}, den)));
+    return r.x + r.y;
+}
+
+// torch.lgamma for finite a > 0
+TCLIP_HD float lgamma_f32(float a) {
+    if (a != a || a == __builtin_inff()) return a;
+    if (!(a > 0.0f)) return __builtin_inff();                // poles / negative: unreachable here
+    if (a < 0.5f) return lgamma_sleef_lt05(a);
+    if (a < 2.3f) return lgamma_sleef_05_23(a);
+    return lgamma_sleef_ge23<false>(a);
+}
+
+// ---------------------------------------------------------------------------------------------
+// torch.sqrt on an AVX-512 host is MKL VML vsSqrt (HA): y = VRSQRT14PS(x), s = x*y,
+// r = fma(fma(-s, s, x), 0.5*y, s) - one Heron correction of a 14-bit estimate, NOT correctly
+// rounded (0.66 % of results are one ulp low).  The reference's alpha update takes its square
+// root there (em_dirichlet.py:166-167: -b + sqrt(b^2 + 4a) cancels, so that ulp is amplified),
+// hence the restatement.  VRSQRT14PS is reproduced from a table of its exact values (a function of
+// exponent parity and the top 15 mantissa bits, tools/gen_rsqrt14_table.c).
+#if defined(__HIP_DEVICE_COMPILE__)
+static __device__ const uint16_t kRsqrt14Tab[65536] = {TCLIP_RSQRT14_TABLE_VALUES};
+#else
+static const uint16_t kRsqrt14Tab[65536] = {TCLIP_RSQRT14_TABLE_VALUES};
+#endif
+
+TCLIP_HD float rsqrt14_f32(float x) {                 // x positive and normal
+    const uint32_t b = f32_bits(x);
+    const int ue = (int)(b >> 23) - 127;
+    const int par = ue & 1, k = (ue - par) >> 1;      // x = m * 4^k, m in [1,4)
+    const uint32_t mant = b & 0x7fffffu;
+    const uint32_t t = kRsqrt14Tab[((uint32_t)par << 15) | (mant >> 8)];
+    const uint32_t yb = (mant == 0u && par == 0) ? 0x3f800000u : (0x3f000000u | (t << 7));
+    return bits_f32(yb - ((uint32_t)k << 23));
+}
+
+TCLIP_HD float sqrt_torch_inrange_f32(float x) {      // x positive normal, exponent in [-100, 100]
+    const float y = rsqrt14_f32(x);
+    const float s = x * y;
+    return __builtin_fmaf(__builtin_fmaf(-s, s, x), 0.5f * y, s);
+}
+
+TCLIP_HD float sqrt_torch_f32(float x) {
+    const uint32_t b = f32_bits(x);
+    if (b >= 0x0d800000u && b <= 0x71800000u) return sqrt_torch_inrange_f32(x);
+    return __builtin_sqrtf(x);                        // zero, subnormal, huge, inf, nan, negative
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -437,12 +440,44 @@ TCLIP_HD float exp_f32_sleef(float d) {
     u = __builtin_fmaf(u, s, 0.166666671633720397949219f);
     u = __builtin_fmaf(u, s, 0.5f);
     u = 1.0f + __builtin_fmaf(s * s, u, s);
-    // ldexp2kf: scale by 2^(q>>1) twice
-    int q1 = q >> 1, q2 = q - q1;
+    int q1 = q >> 1, q2 = q - q1;                      // ldexp2kf: scale by 2^(q>>1) twice
     u = u * bits_f32((uint32_t)(q1 + 127) << 23) * bits_f32((uint32_t)(q2 + 127) << 23);
     if (d < -104.0f) u = 0.0f;
     if (d > 104.0f) u = __builtin_inff();
     return u;
+}
+
+// ---------------------------------------------------------------------------------------------
+// The two special functions of one MM update, fused and branch-free: psi1 = digamma(a+1) exactly
+// as digamma_f32 computes it, lg1 = lgamma(a+1) exactly as lgamma_f32 computes it.
+// Domain: 0 <= a <= 2^40 (then x = a+1, x*x, the reciprocals and every intermediate stay normal
+// and in the range where the fast reciprocal equals the IEEE quotient); callers route anything
+// else (NaN, inf, negative, huge) to the generic routines.
+TCLIP_HD bool mm_fast_domain(float a) { return a >= 0.0f && a <= 0x1p40f; }
+
+TCLIP_HD float digamma_xp1(float a, const LogTabEntry* tab) {
+    float x = a + 1.0f, acc = 0.0f;
+#if defined(__HIP_DEVICE_COMPILE__)
+#pragma unroll
+#endif
+    for (int j = 0; j < 9; j++) {                            // while (x < 10) {acc -= 1/x; x += 1}
+        const bool small = x < 10.0f;
+        const float rxj = rcp_rn_f32(x);
+        acc -= small ? rxj : 0.0f;
+        x += small ? 1.0f : 0.0f;
+    }
+    const float series = digamma_series<true>(x, acc, tab);  // x <= 2^40 + 9 < 1e17
+    return (x == 10.0f) ? acc + 2.25175258906672110764f : series;
+}
+
+TCLIP_HD void digamma_lgamma_xp1(float a, const LogTabEntry* tab, float& psi1, float& lg1) {
+    psi1 = digamma_xp1(a, tab);
+    // a+1 >= 1: the two non-reflected branches of lgammaf_u10, both evaluated, one selected
+    const float x1 = a + 1.0f;
+    const bool lo = x1 < 2.3f;
+    const float small_x = lgamma_sleef_05_23(lo ? x1 : 2.0f);
+    const float large_x = lgamma_sleef_ge23<true>(lo ? 8.0f : x1);
+    lg1 = lo ? small_x : large_x;
 }
 
 }  // namespace tclip
