@@ -252,19 +252,44 @@ struct MMArgs {
 // prefix count), evaluates the expensive branch on the DENSE queue (ceil(n/64) passes instead of
 // E passes over mostly idle lanes), and then every lane picks its results back up.
 // `queue` = 64*E floats of LDS private to this wave.
+// y of a row: in registers for short rows, re-read from global memory (L1/L2 hits, read-only)
+// every iteration for long rows, where 2 x E registers per lane would cost occupancy and spills.
 template <int E>
-__device__ __forceinline__ void mm_iterate(float (&beta)[E], const float (&yv)[E], int K, int lane,
+struct RowY {
+    static constexpr bool kInRegs = E <= 16;
+    float r[kInRegs ? E : 1];
+    const float* g;      // row base in global memory, or nullptr for a dead row (y = -10)
+    int lane, K;
+    __device__ __forceinline__ void load(const float* row_y, int lane_, int K_) {
+        g = row_y; lane = lane_; K = K_;
+        if (kInRegs) {
+#pragma unroll
+            for (int e = 0; e < (kInRegs ? E : 1); e++) {
+                const int d = e * kGroup + lane;
+                r[e] = d < K ? (g ? g[d] : -10.0f) : 0.0f;
+            }
+        }
+    }
+    __device__ __forceinline__ float get(int e) const {
+        if (kInRegs) return r[kInRegs ? e : 0];
+        const int d = e * kGroup + lane;
+        return d < K ? (g ? g[d] : -10.0f) : 0.0f;
+    }
+};
+
+template <int E>
+__device__ __forceinline__ void mm_iterate(float (&beta)[E], const RowY<E>& yv, int K, int lane,
                                            const LogTabEntry* tab, float* queue, bool measure, double& num,
                                            double& den) {
     const float s = group_sum_torch<E>(beta, K, lane);
-    const float psi_s = digamma_pos_f32(s, tab);
-    bool in_domain = psi_s == psi_s;
+    bool in_domain = fast_range_f32(s) && s <= 0x1p40f;
 #pragma unroll
     for (int e = 0; e < E; e++) in_domain = in_domain && mm_fast_domain(beta[e]);
     if (__builtin_expect(!__all(in_domain), 0)) {   // NaN / inf / out of range somewhere in the wave
+        const float psi_s = digamma_f32(s);
 #pragma unroll
         for (int e = 0; e < E; e++) {
-            const float nb = mm_update_generic(beta[e], yv[e], psi_s);
+            const float nb = mm_update_generic(beta[e], yv.get(e), psi_s);
             const bool ok = e * kGroup + lane < K;
             if (measure && ok) {
                 const double df = (double)nb - (double)beta[e];
@@ -275,6 +300,7 @@ __device__ __forceinline__ void mm_iterate(float (&beta)[E], const float (&yv)[E
         }
         return;
     }
+    const float psi_s = digamma_pos_f32(s, tab);   // row sums are mostly >= 10: the recurrence loop is rarely entered
     const unsigned long long lt_mask = (1ull << (threadIdx.x & 63)) - 1ull;
     // phase A: queue the arguments of the expensive lgamma branch
     int n_big = 0;
@@ -310,7 +336,7 @@ __device__ __forceinline__ void mm_iterate(float (&beta)[E], const float (&yv)[E
         base += __popcll(m);
         const float lg_small = lgamma_sleef_05_23(big ? 2.0f : x1);
         const float psi1 = digamma_xp1(a, tab);
-        const float nb = mm_update_algebra(a, yv[e], psi_s, psi1, big ? lg_big : lg_small);
+        const float nb = mm_update_algebra(a, yv.get(e), psi_s, psi1, big ? lg_big : lg_small);
         const bool ok = e * kGroup + lane < K;
         if (measure && ok) {
             const double df = (double)nb - (double)a;
@@ -325,7 +351,7 @@ __device__ __forceinline__ void mm_iterate(float (&beta)[E], const float (&yv)[E
 constexpr int kMaxCycle = 64;  // longest limit cycle looked for on dead rows (periods up to 20 seen at K=1000)
 
 template <int E>
-__global__ __launch_bounds__(256, (E > 20 ? 2 : (E > 8 ? 3 : 4))) void k_mm_chunk(MMArgs a) {
+__global__ __launch_bounds__(256, (E > 8 ? 3 : 4)) void k_mm_chunk(MMArgs a) {
     __shared__ LogTabEntry tab[16];
     __shared__ double cyc[8][kMaxCycle][2];
     __shared__ float lg_queue[4][64 * E];             // per wave: arguments / results of the large-x lgamma
@@ -347,13 +373,13 @@ __global__ __launch_bounds__(256, (E > 20 ? 2 : (E > 8 ? 3 : 4))) void k_mm_chun
             src = a.chunk == 0 ? a.alpha : a.beta_dead;
             dst = a.beta_dead;
         }
-        float beta[E], yv[E];
+        float beta[E];
+        RowY<E> yv;
+        yv.load(alive ? a.y + (size_t)row * K : nullptr, lane, K);
 #pragma unroll
         for (int e = 0; e < E; e++) {
             const int d = e * kGroup + lane;
-            const bool ok = d < K;
-            beta[e] = ok ? src[(size_t)row * K + d] : 0.0f;
-            yv[e] = ok ? (alive ? a.y[(size_t)row * K + d] : -10.0f) : 0.0f;
+            beta[e] = d < K ? src[(size_t)row * K + d] : 0.0f;
         }
         double num = 0.0, den = 0.0;
         for (int l = a.l0; l <= a.l1; l++) mm_iterate<E>(beta, yv, K, lane, tab, queue, a.has_check && l == a.l1, num, den);
