@@ -92,7 +92,7 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
-    dist_on = world > 1
+    dist_on = "RANK" in os.environ          # launched by torch.distributed.run (any world size)
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the EM-Dirichlet engine has no CPU path")
     torch.cuda.set_device(local_rank)
