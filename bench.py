@@ -13,7 +13,9 @@ own 1000 tasks (independent batches, no data-path collective).
 
 Extra objects on the JSON line:
   roofline     the dominant kernel k_mm_chunk, timed live with HIP events around each of its
-               launches.  The path is fp32 vector-ALU bound, so the bound is
+               launches on the streams they run on (independent batches use a few internal
+               streams, so launches overlap: `achieved` divides by the time during which at least
+               one launch was running, `avg_launch_ms` is the plain mean launch duration).  The path is fp32 vector-ALU bound, so the bound is
                "valu": achieved = 48 flop-equivalents x element-updates executed / kernel time,
                peak = 157.3 TFLOP/s (fp32 vector, MI355X_MICROARCH.md); the compulsory HBM bytes
                of the same launches are reported beside it as hbm_* against 8 TB/s.
@@ -129,7 +131,7 @@ def main():
         res, acc = step()
     fence()
     elapsed = time.perf_counter() - t0
-    mm_ms, mm_launches, updates = engine.profile_collect()
+    mm_ms, mm_launch_sum, mm_launches, updates = engine.profile_collect()
     engine.profile_enable(False)
     if dist_on:
         t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
@@ -161,8 +163,9 @@ def main():
                          "flop_eq_per_element_update": FLOP_EQ_PER_UPDATE,
                          "element_updates_executed_per_step": updates / steps,
                          "element_updates_reference_semantics_per_step": ref_updates,
-                         "kernel_ms_per_step": mm_ms / steps, "launches_per_step": mm_launches / steps,
-                         "avg_launch_ms": mm_ms / max(mm_launches, 1),
+                         "kernel_busy_ms_per_step": mm_ms / steps, "launches_per_step": mm_launches / steps,
+                         "avg_launch_ms": mm_launch_sum / max(mm_launches, 1),
+                         "launch_overlap": mm_launch_sum / mm_ms if mm_ms > 0 else 0.0,
                          "hbm_algorithmic_GBps": rows_bytes / (mm_ms * 1e-3) / 1e9 if mm_ms > 0 else 0.0,
                          "hbm_frac": (rows_bytes / (mm_ms * 1e-3) / 1e9) / PEAK_HBM_GBS if mm_ms > 0 else 0.0},
         }

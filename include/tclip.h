@@ -100,11 +100,14 @@ int tclip_gather_rows(const float* table, int64_t n_rows, int32_t n_class, const
 
 /* Optional instrumentation used by bench.py (thread-local, off by default).  While enabled,
  * every launch of the majorize-minimize kernel issued by tclip_em_dirichlet_run on this thread is
- * bracketed by HIP events on the caller's stream and the element-updates it executes are counted
- * on the device.  tclip_profile_collect synchronises the device, returns the summed kernel time,
- * the number of launches and the element-update count since the last collection, and resets. */
+ * bracketed by HIP events on the stream it is launched on (independent batches run on a few
+ * internal streams, so launches overlap) and the element-updates it executes are counted on the
+ * device.  tclip_profile_collect synchronises the device and returns, since the last collection:
+ * the time during which at least one such launch was running (union of the intervals), the sum
+ * of the individual launch durations, the number of launches and the element-update count. */
 int tclip_profile_enable(int on);
-int tclip_profile_collect(double* mm_kernel_ms, int64_t* mm_launches, int64_t* element_updates);
+int tclip_profile_collect(double* mm_busy_ms, double* mm_launch_ms_sum, int64_t* mm_launches,
+                          int64_t* element_updates);
 
 /* Device self-test (used by tests/test_gpu_primitives.py).  out host [14]:
  *   [0] 1/x: fast exact reciprocal vs IEEE quotient, every float of a binade at 3 exponents

@@ -15,7 +15,7 @@ for rep in range(2):
     torch.cuda.synchronize(); t = time.time()
     engine.profile_enable(True)
     res = engine.run_em_dirichlet(x_q, n_batches=B, iters=iters, iter_mm=1000, lambd=int(K / 5) * 75, hard=hard)
-    ms, n, upd = engine.profile_collect()
+    ms, ms_sum, n, upd = engine.profile_collect()
     engine.profile_enable(False)
     print(f"K={K} B={B} N={N} iters={iters} total={time.time()-t:.3f}s mm_ms={ms:.1f} launches={n} updates={upd:.3e} "
           f"updates/s={upd/ms*1e3:.3e} mm_iters={res.mm_iters[0].tolist()}", flush=True)

@@ -17,6 +17,8 @@
 #include <stdio.h>
 #include <string.h>
 
+#include <algorithm>
+#include <utility>
 #include <vector>
 
 #include "../../include/tclip.h"
@@ -877,26 +879,17 @@ extern "C" {
 int tclip_abi_version(void) { return TCLIP_ABI_VERSION; }
 const char* tclip_last_error(void) { return g_err; }
 
-size_t tclip_workspace_bytes(const tclip_problem* p) {
-    if (check_problem(p) != TCLIP_OK) return 0;
-    return make_layout(*p).total;
-}
+}  // extern "C"
 
-int tclip_em_dirichlet_run(const tclip_problem* pp, const float* x_q, const float* x_s, const int64_t* y_s, float* u,
+namespace tclip {
+
+// Enqueues the whole loop for `p.n_batches` consecutive batches on stream `st`.  `crit_stride` is
+// the row stride (= iters of the full problem) of criterions / mm_iters.
+static int enqueue_batches(const tclip_problem& p, const float* x_q, const float* x_s, const int64_t* y_s, float* u,
                            float* v, float* alpha, int32_t* preds, float* criterions, int32_t* mm_iters,
-                           void* workspace, size_t workspace_bytes, void* stream) {
-    if (int rc = check_problem(pp)) return rc;
-    const tclip_problem p = *pp;
+                           char* ws, hipStream_t st) {
     const bool zs = p.n_support == 0;
-    if (!x_q || !u || !v || !alpha || !preds || !criterions || !mm_iters || !workspace)
-        return fail(TCLIP_ERR_ARG, "null pointer argument");
-    if (zs != (x_s == nullptr) || zs != (y_s == nullptr))
-        return fail(TCLIP_ERR_ARG, "x_s and y_s must be given exactly when n_support > 0");
     const Layout L = make_layout(p);
-    if (workspace_bytes < L.total) return fail(TCLIP_ERR_WORKSPACE, "workspace smaller than tclip_workspace_bytes()");
-    if (((uintptr_t)workspace & 255) != 0) return fail(TCLIP_ERR_WORKSPACE, "workspace must be 256-byte aligned");
-    hipStream_t st = (hipStream_t)stream;
-    char* ws = (char*)workspace;
     const int B = p.n_batches, N = p.tasks_per_batch, Q = p.n_query, K = p.n_class, S = p.n_support;
     const int T = B * N, TK = T * K;
     const size_t TQK = (size_t)T * Q * K, TKK = (size_t)T * K * K;
@@ -995,6 +988,93 @@ int tclip_em_dirichlet_run(const tclip_problem* pp, const float* x_q, const floa
     return TCLIP_OK;
 }
 
+// Independent batches are spread over a few internal HIP streams (forked from and joined to the
+// caller's stream with events): every MM launch is a barrier for the batches it covers, and with
+// equal-length rows its last round of waves leaves SIMDs idle; kernels of another group fill them.
+constexpr int kMaxGroups = 4;
+struct StreamPool {
+    hipStream_t s[kMaxGroups] = {};
+    hipEvent_t fork = nullptr, join[kMaxGroups] = {};
+    bool ready = false;
+};
+thread_local StreamPool g_pool;
+
+static int pool_init() {
+    if (g_pool.ready) return TCLIP_OK;
+    for (int i = 0; i < kMaxGroups; i++) {
+        TCLIP_HIP(hipStreamCreateWithFlags(&g_pool.s[i], hipStreamNonBlocking));
+        TCLIP_HIP(hipEventCreateWithFlags(&g_pool.join[i], hipEventDisableTiming));
+    }
+    TCLIP_HIP(hipEventCreateWithFlags(&g_pool.fork, hipEventDisableTiming));
+    g_pool.ready = true;
+    return TCLIP_OK;
+}
+
+static int n_groups_of(const tclip_problem& p) { return p.n_batches < kMaxGroups ? p.n_batches : kMaxGroups; }
+
+static tclip_problem group_problem(const tclip_problem& p, int g, int* first_batch) {
+    const int G = n_groups_of(p), base = p.n_batches / G, extra = p.n_batches % G;
+    tclip_problem q = p;
+    q.n_batches = base + (g < extra ? 1 : 0);
+    *first_batch = g * base + (g < extra ? g : extra);
+    return q;
+}
+
+}  // namespace tclip
+
+extern "C" {
+
+size_t tclip_workspace_bytes(const tclip_problem* p) {
+    if (check_problem(p) != TCLIP_OK) return 0;
+    size_t total = 0;
+    for (int g = 0; g < n_groups_of(*p); g++) {
+        int b0;
+        total += make_layout(group_problem(*p, g, &b0)).total;
+    }
+    return total;
+}
+
+int tclip_em_dirichlet_run(const tclip_problem* pp, const float* x_q, const float* x_s, const int64_t* y_s, float* u,
+                           float* v, float* alpha, int32_t* preds, float* criterions, int32_t* mm_iters,
+                           void* workspace, size_t workspace_bytes, void* stream) {
+    if (int rc = check_problem(pp)) return rc;
+    const tclip_problem p = *pp;
+    const bool zs = p.n_support == 0;
+    if (!x_q || !u || !v || !alpha || !preds || !criterions || !mm_iters || !workspace)
+        return fail(TCLIP_ERR_ARG, "null pointer argument");
+    if (zs != (x_s == nullptr) || zs != (y_s == nullptr))
+        return fail(TCLIP_ERR_ARG, "x_s and y_s must be given exactly when n_support > 0");
+    if (workspace_bytes < tclip_workspace_bytes(pp)) return fail(TCLIP_ERR_WORKSPACE, "workspace smaller than tclip_workspace_bytes()");
+    if (((uintptr_t)workspace & 255) != 0) return fail(TCLIP_ERR_WORKSPACE, "workspace must be 256-byte aligned");
+    hipStream_t caller = (hipStream_t)stream;
+    const int G = n_groups_of(p);
+    if (G > 1) {
+        if (int rc = pool_init()) return rc;
+        TCLIP_HIP(hipEventRecord(g_pool.fork, caller));
+    }
+    char* ws = (char*)workspace;
+    const size_t N = p.tasks_per_batch, Q = p.n_query, K = p.n_class, S = p.n_support;
+    for (int g = 0; g < G; g++) {
+        int b0;
+        const tclip_problem q = group_problem(p, g, &b0);
+        const size_t t0 = (size_t)b0 * N;
+        hipStream_t st = G > 1 ? g_pool.s[g] : caller;
+        if (G > 1) TCLIP_HIP(hipStreamWaitEvent(st, g_pool.fork, 0));
+        tclip_problem qs = q;
+        qs.iters = p.iters;
+        if (int rc = enqueue_batches(qs, x_q + t0 * Q * K, zs ? nullptr : x_s + t0 * S * K, zs ? nullptr : y_s + t0 * S,
+                                     u + t0 * Q * K, v + t0 * K, alpha + t0 * K * K, preds + t0 * Q,
+                                     criterions + (size_t)b0 * p.iters, mm_iters + (size_t)b0 * p.iters, ws, st))
+            return rc;
+        ws += make_layout(q).total;
+        if (G > 1) {
+            TCLIP_HIP(hipEventRecord(g_pool.join[g], st));
+            TCLIP_HIP(hipStreamWaitEvent(caller, g_pool.join[g], 0));
+        }
+    }
+    return TCLIP_OK;
+}
+
 int tclip_profile_enable(int on) {
     if (on && !g_prof.counter) {
         TCLIP_HIP(hipMalloc((void**)&g_prof.counter, sizeof(unsigned long long)));
@@ -1004,15 +1084,34 @@ int tclip_profile_enable(int on) {
     return TCLIP_OK;
 }
 
-int tclip_profile_collect(double* mm_kernel_ms, int64_t* mm_launches, int64_t* element_updates) {
+int tclip_profile_collect(double* mm_busy_ms, double* mm_launch_ms_sum, int64_t* mm_launches,
+                          int64_t* element_updates) {
     TCLIP_HIP(hipDeviceSynchronize());
-    double ms = 0.0;
+    // launches of different batch groups overlap on their streams: report both the sum of the
+    // individual launch durations and the length of the union of the [start, end] intervals
+    std::vector<std::pair<float, float>> iv;
+    double sum = 0.0;
     for (size_t i = 0; i + 1 < g_prof.used; i += 2) {
-        float t = 0.f;
-        TCLIP_HIP(hipEventElapsedTime(&t, g_prof.ev[i], g_prof.ev[i + 1]));
-        ms += t;
+        float t0 = 0.f, t1 = 0.f;
+        TCLIP_HIP(hipEventElapsedTime(&t0, g_prof.ev[0], g_prof.ev[i]));
+        TCLIP_HIP(hipEventElapsedTime(&t1, g_prof.ev[0], g_prof.ev[i + 1]));
+        iv.emplace_back(t0, t1);
+        sum += (double)t1 - (double)t0;
     }
-    if (mm_kernel_ms) *mm_kernel_ms = ms;
+    std::sort(iv.begin(), iv.end());
+    double busy = 0.0, cur_lo = 0.0, cur_hi = -1.0;
+    for (auto& x : iv) {
+        if (cur_hi < cur_lo || x.first > cur_hi) {
+            if (cur_hi >= cur_lo) busy += cur_hi - cur_lo;
+            cur_lo = x.first;
+            cur_hi = x.second;
+        } else if (x.second > cur_hi) {
+            cur_hi = x.second;
+        }
+    }
+    if (cur_hi >= cur_lo) busy += cur_hi - cur_lo;
+    if (mm_busy_ms) *mm_busy_ms = busy;
+    if (mm_launch_ms_sum) *mm_launch_ms_sum = sum;
     if (mm_launches) *mm_launches = (int64_t)(g_prof.used / 2);
     unsigned long long c = 0;
     if (g_prof.counter) {

@@ -25,8 +25,8 @@ _SIGNATURES = {
     "tclip_gather_rows": (ctypes.c_int, [_P, ctypes.c_int64, ctypes.c_int32, _P, ctypes.c_int64, _P, _P]),
     "tclip_selftest_primitives": (ctypes.c_int, [ctypes.POINTER(ctypes.c_uint64)]),
     "tclip_profile_enable": (ctypes.c_int, [ctypes.c_int]),
-    "tclip_profile_collect": (ctypes.c_int, [ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_int64),
-                                             ctypes.POINTER(ctypes.c_int64)]),
+    "tclip_profile_collect": (ctypes.c_int, [ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_double),
+                                             ctypes.POINTER(ctypes.c_int64), ctypes.POINTER(ctypes.c_int64)]),
 }
 EXPORTS = tuple(_SIGNATURES)
 _lib = None

@@ -121,8 +121,9 @@ def profile_enable(on=True):
 
 
 def profile_collect():
-    """(mm_kernel_ms, mm_launches, element_updates) since the last call; synchronises the device."""
-    ms, n, upd = ctypes.c_double(0), ctypes.c_int64(0), ctypes.c_int64(0)
-    _capi.check(_capi.lib().tclip_profile_collect(ctypes.byref(ms), ctypes.byref(n), ctypes.byref(upd)),
-                "tclip_profile_collect")
-    return ms.value, n.value, upd.value
+    """(mm_busy_ms, mm_launch_ms_sum, mm_launches, element_updates) since the last call;
+    synchronises the device."""
+    busy, total, n, upd = ctypes.c_double(0), ctypes.c_double(0), ctypes.c_int64(0), ctypes.c_int64(0)
+    _capi.check(_capi.lib().tclip_profile_collect(ctypes.byref(busy), ctypes.byref(total), ctypes.byref(n),
+                                                  ctypes.byref(upd)), "tclip_profile_collect")
+    return busy.value, total.value, n.value, upd.value
