@@ -98,6 +98,15 @@ int tclip_match_clusters_host(int32_t n_task, int32_t n_query, int32_t n_class, 
 int tclip_gather_rows(const float* table, int64_t n_rows, int32_t n_class, const int64_t* idx,
                       int64_t n_out, float* out, void* stream);
 
+/* SOFT_KMEANS on probability features (reference: src/methods/zero_shot/soft_kmeans.py:105-220;
+ * BASELINE config 3's second method).  Uses p->n_batches * p->tasks_per_batch tasks, n_query,
+ * n_class and iters; n_support must be 0; the other fields are ignored.  temperature = args.T.
+ *   x_q device [T,Q,K] f32;  u device [T,Q,K] out;  w device [T,K,K] out (centroids);
+ *   preds device [T,Q] i32 out.  The criterion the reference logs is identically 0. */
+size_t tclip_soft_kmeans_workspace_bytes(const tclip_problem* p);
+int tclip_soft_kmeans_run(const tclip_problem* p, const float* x_q, float temperature, float* u, float* w,
+                          int32_t* preds, void* workspace, size_t workspace_bytes, void* stream);
+
 /* Optional instrumentation used by bench.py (thread-local, off by default).  While enabled,
  * every launch of the majorize-minimize kernel issued by tclip_em_dirichlet_run on this thread is
  * bracketed by HIP events on the stream it is launched on (independent batches run on a few

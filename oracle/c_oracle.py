@@ -44,3 +44,13 @@ def run(x_q, x_s=None, y_s=None, *, iters, iter_mm=1000, lambd, hard=False):
     lib().tclip_oracle_run(_ptr(z), _ptr(xs), _ptr(ys), N, Q, K, S, iters, iter_mm, int(lambd), int(bool(hard)),
                            _ptr(u), _ptr(v), _ptr(alpha), _ptr(crit), _ptr(mm), _ptr(am))
     return {"u": u, "v": v, "alpha": alpha, "criterions": crit, "mm_iters": mm, "argmax": am}
+
+
+def run_soft_kmeans(x_q, *, iters, temperature):
+    z = np.ascontiguousarray(x_q, np.float32)
+    N, Q, K = z.shape
+    u = np.empty((N, Q, K), np.float32)
+    w = np.empty((N, K, K), np.float32)
+    am = np.empty((iters, N, Q), np.int16)
+    lib().tclip_oracle_soft_kmeans(_ptr(z), N, Q, K, iters, int(temperature), _ptr(u), _ptr(w), _ptr(am))
+    return {"u": u, "w": w, "argmax": am}

@@ -164,3 +164,27 @@ def clustering_accuracy(u, x_q, y_q, n_class, graph_matching=True):
             new_preds[n] = protos[n].argmax(dim=-1)[preds[n]]
     acc = (new_preds == y_q).float().mean(1, keepdim=True)
     return acc, new_preds
+
+
+def run_soft_kmeans(x_q, *, n_class, iters, temperature):
+    """SOFT_KMEANS on probability features, the reference's torch op sequence
+    (src/methods/zero_shot/soft_kmeans.py:105-220): w = u^T z / sum u (empty clusters keep their
+    centroid), u = softmax_k(-T/2 ||w_k - z_q||^2).  Returns dict(u, w, criterions, seconds);
+    the logged criterion is identically 0 (the reference compares u with a copy of itself)."""
+    query = x_q.clone().float()
+    t0 = time.time()
+    u = query.clone()
+    num = (query.unsqueeze(2) * u.unsqueeze(3)).sum(1)
+    den = u.sum(1).clamp(min=EPS)
+    w = num.div_(den.unsqueeze(2))
+    criterions = []
+    for _ in range(iters):
+        num = (query.unsqueeze(2) * u.unsqueeze(3)).sum(1)
+        den = u.sum(1).clamp(min=EPS)
+        live = u.sum(1).unsqueeze(-1) > EPS
+        w = num.div_(den.unsqueeze(2)) * live + (w * (1 - 1 * live))
+        diff = w.unsqueeze(1) - query.unsqueeze(2)
+        logits = -1 / 2 * (diff.square_()).sum(dim=-1)
+        u = (temperature * logits).softmax(2)
+        criterions.append((u.clone() - u).norm(dim=(1, 2)).mean(0))
+    return {"u": u, "w": w, "criterions": torch.stack(criterions), "seconds": time.time() - t0}

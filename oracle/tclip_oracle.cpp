@@ -302,6 +302,53 @@ int tclip_oracle_run(const float* z, const float* xs, const int64_t* ys, int N, 
     return 0;
 }
 
+// SOFT_KMEANS (src/methods/zero_shot/soft_kmeans.py:105-220), one batch; w [N,K,K] centroids out.
+int tclip_oracle_soft_kmeans(const float* z, int N, int Q, int K, int iters, int temperature, float* u, float* w,
+                             int16_t* argmax_trace) {
+    const size_t NQK = (size_t)N * Q * K;
+    for (size_t i = 0; i < NQK; i++) u[i] = z[i];
+    std::vector<float> logit(K), ex(K);
+    for (int it = -1; it < iters; it++) {            // it = -1: w_init (every row written)
+        for (int n = 0; n < N; n++)
+            for (int k = 0; k < K; k++) {
+                const float* un = u + (size_t)n * Q * K;
+                const float* zn = z + (size_t)n * Q * K;
+                const float c = sum_outer(Q, k, K, [&](long q) { return un[q * K + k]; });
+                const bool alive = c > kEps;
+                const float den = c < kEps ? kEps : c;
+                float* wr = w + ((size_t)n * K + k) * K;
+                for (int d = 0; d < K; d++) {
+                    const float t = sum_outer(Q, (long)k * K + d, (long)K * K,
+                                              [&](long q) { return zn[q * K + d] * un[q * K + k]; }) / den;
+                    if (it < 0) wr[d] = t;
+                    else wr[d] = alive ? (t * 1.0f + wr[d] * 0.0f) : (t * 0.0f + wr[d] * 1.0f);
+                }
+            }
+        if (it < 0) continue;
+        for (int n = 0; n < N; n++)
+            for (int q = 0; q < Q; q++) {
+                const float* zq = z + ((size_t)n * Q + q) * K;
+                float mx = -INFINITY;
+                for (int k = 0; k < K; k++) {
+                    const float* wr = w + ((size_t)n * K + k) * K;
+                    const float s = sum_inner(K, [&](long d) { const float df = wr[d] - zq[d]; return df * df; });
+                    logit[k] = (float)temperature * (-0.5f * s);
+                    mx = logit[k] > mx ? logit[k] : mx;
+                }
+                for (int k = 0; k < K; k++) ex[k] = tclip::exp_f32_sleef(logit[k] - mx);
+                const float inv = 1.0f / sum_reduce_all(ex.data(), K);
+                float* ur = u + ((size_t)n * Q + q) * K;
+                int best = 0;
+                for (int k = 0; k < K; k++) {
+                    ur[k] = ex[k] * inv;
+                    if (ur[k] > ur[best]) best = k;
+                }
+                if (argmax_trace) argmax_trace[((size_t)it * N + n) * Q + q] = (int16_t)best;
+            }
+    }
+    return 0;
+}
+
 // exposed for unit tests of the reduction-order emulation
 float tclip_oracle_sum_inner(const float* x, long n) { return sum_inner(n, [&](long i) { return x[i]; }); }
 float tclip_oracle_sum_outer(const float* x, long n, long col, long ncols) { return sum_outer(n, col, ncols, [&](long i) { return x[i]; }); }

@@ -51,8 +51,9 @@ def load_reference_classes():
     from src.methods.zero_shot.hard_em_dirichlet import HARD_EM_DIRICHLET as ZSH
     from src.methods.few_shot.em_dirichlet import EM_DIRICHLET as FS
     from src.methods.few_shot.hard_em_dirichlet import HARD_EM_DIRICHLET as FSH
+    from src.methods.zero_shot.soft_kmeans import SOFT_KMEANS as SKM
     sys.path.pop(0)
-    return {"zs_soft": ZS, "zs_hard": ZSH, "fs_soft": FS, "fs_hard": FSH}
+    return {"zs_soft": ZS, "zs_hard": ZSH, "fs_soft": FS, "fs_hard": FSH, "zs_skm": SKM}
 
 
 # name: (kind, K, N, iters, shots, seed, full_alpha)
@@ -67,6 +68,10 @@ SMALL = {
     "fs_soft_K37_N3_s2": ("fs_soft", 37, 3, 20, 2, 2021, True),
     "fs_hard_K10_N4_s4": ("fs_hard", 10, 4, 10, 4, 2020, True),
     "fs_hard_K37_N3_s3": ("fs_hard", 37, 3, 10, 3, 2021, True),
+    "zs_skm_K10_N4": ("zs_skm", 10, 4, 20, 0, 2020, True),
+    "zs_skm_K37_N6": ("zs_skm", 37, 6, 20, 0, 2021, True),
+    "zs_skm_K100_N4": ("zs_skm", 100, 4, 20, 0, 2022, True),
+    "zs_skm_K397_N2": ("zs_skm", 397, 2, 20, 0, 2023, True),
 }
 LARGE = {
     "zs_hard_K397_N2": ("zs_hard", 397, 2, 10, 0, 2023, False),
@@ -107,7 +112,8 @@ def run_case(name, spec, classes):
             norm_vals.append(float(r))
         return r
 
-    real_update_alpha = m.update_alpha
+    is_skm = kind == "zs_skm"
+    real_update_alpha = None if is_skm else m.update_alpha
 
     def traced_update_alpha(alpha_0, y_cst):
         sqrt_calls[0] = 0
@@ -126,7 +132,8 @@ def run_case(name, spec, classes):
         real_u_update(q)
         trace["argmax"].append(m.u.argmax(2).to(torch.int16).numpy().copy())
 
-    m.update_alpha = traced_update_alpha
+    if not is_skm:
+        m.update_alpha = traced_update_alpha
     m.u_update = traced_u_update
     torch.sqrt = counting_sqrt
     torch.norm = recording_norm
@@ -138,17 +145,17 @@ def run_case(name, spec, classes):
         torch.norm = real_norm
     dt = time.time() - t0
 
-    alpha = m.alpha.numpy()
+    alpha = m.w.numpy() if is_skm else m.alpha.numpy()      # soft k-means: the centroids
     out = {
         "kind": kind, "K": K, "N": N, "iters": iters, "iter_mm": 1000, "shots": shots, "seed": seed,
         "x_q": x_q.numpy(), "y_q": y_q.numpy(),
         "mm_iters": np.asarray(trace["mm_iters"], np.int32),
         "argmax": np.stack(trace["argmax"]),            # (iters, N, Q) int16
-        "live": np.stack(trace["live"]),                # (iters, N, K) bool
-        "stop_test": np.stack(trace["stop_test"]),      # (iters, 19, 2) norms seen by the MM stop test
+        "live": np.stack(trace["live"]) if trace["live"] else np.zeros(0),            # (iters, N, K) bool
+        "stop_test": np.stack(trace["stop_test"]) if trace["stop_test"] else np.zeros(0),   # norms seen by the MM stop test
         "criterions": np.asarray(logs["criterions"], np.float32),
         "acc": np.asarray(logs["acc"], np.float32),
-        "v": m.v.numpy(),
+        "v": np.zeros(0) if is_skm else m.v.numpy(),
         "torch_version": torch.__version__, "ref_seconds": dt,
     }
     if few:

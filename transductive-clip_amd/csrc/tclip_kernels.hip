@@ -554,6 +554,39 @@ __global__ __launch_bounds__(256) void k_logits(const float* __restrict__ alpha,
     }
 }
 
+// SOFT_KMEANS E-step (soft_kmeans.py:105-125): logit[t,q,k] = T * (-1/2 * sum_d (w[t,k,d] - z[t,q,d])^2),
+// the sum in torch's last-dim order.  Same structure as k_logits.
+template <int E>
+__global__ __launch_bounds__(256) void k_kmeans_logits(const float* __restrict__ w, const float* __restrict__ z,
+                                                       const int32_t* __restrict__ rows, const int32_t* __restrict__ n_rows,
+                                                       int Q, int K, float temperature, float* __restrict__ logit0) {
+    const int lane = threadIdx.x & (kGroup - 1);
+    const int group = threadIdx.x / kGroup, groups_per_block = blockDim.x / kGroup;
+    const int n = *n_rows;
+    for (int i = blockIdx.x; i < n; i += gridDim.x) {
+        const int row = rows[i];
+        const int t = row / K, k = row % K;
+        float wv[E];
+#pragma unroll
+        for (int e = 0; e < E; e++) {
+            const int d = e * kGroup + lane;
+            wv[e] = d < K ? w[(size_t)row * K + d] : 0.0f;
+        }
+        for (int q = group; q < Q; q += groups_per_block) {
+            const float* zq = z + ((size_t)t * Q + q) * K;
+            float pr[E];
+#pragma unroll
+            for (int e = 0; e < E; e++) {
+                const int d = e * kGroup + lane;
+                const float df = d < K ? wv[e] - zq[d] : 0.0f;
+                pr[e] = df * df;
+            }
+            const float ssum = group_sum_torch<E>(pr, K, lane);
+            if (lane == 0) logit0[((size_t)t * Q + q) * K + k] = temperature * (-0.5f * ssum);
+        }
+    }
+}
+
 // E-step, part 3: u = softmax_k(logit0 + (lambd * v) / Q), torch CPU softmax order
 // (max, Sleef expf of the shifted row, 16-lane strided sum + butterfly, one reciprocal).
 // One 16-lane group per (task, query) row.  Also argmax (first maximum) and the hard one-hot.
@@ -565,12 +598,12 @@ __global__ __launch_bounds__(256) void k_softmax(const float* __restrict__ logit
     if (r >= TQ) return;
     const int t = r / Q;
     const float* x = logit0 + (size_t)r * K;
-    const float* vt = v + (size_t)t * K;
+    const float* vt = v ? v + (size_t)t * K : nullptr;
     float* ur = u + (size_t)r * K;
     const float qf = (float)Q;
     float mx = -__builtin_inff();
     for (int k = lane; k < K; k += 16) {
-        const float val = x[k] + (lambd * vt[k]) / qf;
+        const float val = v ? x[k] + (lambd * vt[k]) / qf : x[k];
         ur[k] = val;
         mx = val > mx ? val : mx;
     }
@@ -865,6 +898,13 @@ template <int E> struct LaunchLogits {
     }
 };
 
+template <int E> struct LaunchKmeansLogits {
+    static void run(int grid, hipStream_t st, const float* w, const float* z, const int32_t* rows, const int32_t* n,
+                    int Q, int K, float temperature, float* logit0) {
+        hipLaunchKernelGGL(k_kmeans_logits<E>, dim3(grid), dim3(256), 0, st, w, z, rows, n, Q, K, temperature, logit0);
+    }
+};
+
 static int ew_grid(size_t n) {
     size_t g = (n + 255) / 256;
     return (int)(g > 8192 ? 8192 : (g < 1 ? 1 : g));
@@ -1072,6 +1112,75 @@ int tclip_em_dirichlet_run(const tclip_problem* pp, const float* x_q, const floa
             TCLIP_HIP(hipStreamWaitEvent(caller, g_pool.join[g], 0));
         }
     }
+    return TCLIP_OK;
+}
+
+// ---- SOFT_KMEANS (BASELINE config 3's second method)
+static size_t kmeans_ws_parts(const tclip_problem& p, size_t* o_cs, size_t* o_live, size_t* o_ones, size_t* o_logit,
+                              size_t* o_rows, size_t* o_scratch_rows, size_t* o_counts) {
+    const size_t T = (size_t)p.n_batches * p.tasks_per_batch, K = p.n_class, Q = p.n_query;
+    size_t o = 0;
+    auto take = [&](size_t bytes) { size_t r = o; o += align_up(bytes); return r; };
+    *o_cs = take(T * K * 4);
+    *o_live = take(T * K);
+    *o_ones = take(T * K);
+    *o_logit = take(T * Q * K * 4);
+    *o_rows = take(T * K * 4);
+    *o_scratch_rows = take(T * K * 4);
+    *o_counts = take(256);
+    return o;
+}
+
+size_t tclip_soft_kmeans_workspace_bytes(const tclip_problem* p) {
+    if (check_problem(p) != TCLIP_OK) return 0;
+    size_t a, b, c, d, e, f, g;
+    return kmeans_ws_parts(*p, &a, &b, &c, &d, &e, &f, &g);
+}
+
+int tclip_soft_kmeans_run(const tclip_problem* pp, const float* x_q, float temperature, float* u, float* w,
+                          int32_t* preds, void* workspace, size_t workspace_bytes, void* stream) {
+    if (int rc = check_problem(pp)) return rc;
+    const tclip_problem p = *pp;
+    if (!x_q || !u || !w || !preds || !workspace) return fail(TCLIP_ERR_ARG, "null pointer argument");
+    if (p.n_support != 0) return fail(TCLIP_ERR_ARG, "SOFT_KMEANS is a zero-shot method: n_support must be 0");
+    size_t o_cs, o_live, o_ones, o_logit, o_rows, o_scratch, o_counts;
+    const size_t total = kmeans_ws_parts(p, &o_cs, &o_live, &o_ones, &o_logit, &o_rows, &o_scratch, &o_counts);
+    if (workspace_bytes < total) return fail(TCLIP_ERR_WORKSPACE, "workspace smaller than tclip_soft_kmeans_workspace_bytes()");
+    if (((uintptr_t)workspace & 255) != 0) return fail(TCLIP_ERR_WORKSPACE, "workspace must be 256-byte aligned");
+    hipStream_t st = (hipStream_t)stream;
+    char* ws = (char*)workspace;
+    const int Q = p.n_query, K = p.n_class, T = p.n_batches * p.tasks_per_batch, TK = T * K;
+    const size_t TQK = (size_t)T * Q * K;
+    float* cs = (float*)(ws + o_cs);
+    uint8_t* live = (uint8_t*)(ws + o_live);
+    uint8_t* ones = (uint8_t*)(ws + o_ones);
+    float* logit0 = (float*)(ws + o_logit);
+    int32_t* rows = (int32_t*)(ws + o_rows);
+    int32_t* scratch_rows = (int32_t*)(ws + o_scratch);
+    int32_t* counts = (int32_t*)(ws + o_counts);
+    hipLaunchKernelGGL(k_copy, dim3(ew_grid(TQK)), dim3(256), 0, st, x_q, u, TQK);          // u = z
+    TCLIP_HIP(hipMemsetAsync(ones, 1, (size_t)TK, st));
+    // w_init: every centroid = u^T z / clamp(sum u)                             (soft_kmeans.py:137-149)
+    hipLaunchKernelGGL(k_cluster_sizes, dim3((TK + 255) / 256), dim3(256), 0, st, (const float*)u, T, Q, K, 1, cs, live,
+                       (float*)nullptr, (int32_t*)nullptr);
+    hipLaunchKernelGGL(k_mstats, dim3((K + 63) / 64, K, T), dim3(64), 0, st, (const float*)u, x_q, (const float*)cs,
+                       (const uint8_t*)ones, (const float*)nullptr, (const float*)nullptr, Q, K, w);
+    for (int it = 0; it < p.iters; it++) {
+        // w_update: live clusters get the new mean, empty ones keep their centroid   (:151-168)
+        hipLaunchKernelGGL(k_cluster_sizes, dim3((TK + 255) / 256), dim3(256), 0, st, (const float*)u, T, Q, K, 1, cs,
+                           live, (float*)nullptr, (int32_t*)nullptr);
+        hipLaunchKernelGGL(k_mstats, dim3((K + 63) / 64, K, T), dim3(64), 0, st, (const float*)u, x_q, (const float*)cs,
+                           (const uint8_t*)live, (const float*)nullptr, (const float*)nullptr, Q, K, w);
+        // distances only for centroids that moved (all of them in the first iteration)
+        TCLIP_HIP(hipMemsetAsync(counts, 0, 256, st));
+        hipLaunchKernelGGL(k_build_rows, dim3((TK + 255) / 256), dim3(256), 0, st, (const uint8_t*)(it == 0 ? ones : live),
+                           (const int32_t*)nullptr, TK, 0, scratch_rows, rows, counts);
+        dispatch_E<LaunchKmeansLogits>(K, TK > 16384 ? 16384 : TK, st, (const float*)w, x_q, (const int32_t*)rows,
+                                       (const int32_t*)(counts + 1), Q, K, temperature, logit0);
+        hipLaunchKernelGGL(k_softmax, dim3((T * Q * 16 + 255) / 256), dim3(256), 0, st, (const float*)logit0,
+                           (const float*)nullptr, T * Q, Q, K, 0.0f, 0, u, preds);
+    }
+    TCLIP_HIP(hipGetLastError());
     return TCLIP_OK;
 }
 

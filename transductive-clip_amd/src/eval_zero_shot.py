@@ -12,11 +12,12 @@ import torch
 
 from src.methods.zero_shot.em_dirichlet import EM_DIRICHLET
 from src.methods.zero_shot.hard_em_dirichlet import HARD_EM_DIRICHLET
+from src.methods.zero_shot.soft_kmeans import SOFT_KMEANS
 from src.sampler_zero_shot import CategoriesSampler_zero_shot, SamplerQuery_zero_shot
 from src.utils import Logger, compute_confidence_interval
 from tclip_amd import engine, sharding
 
-_METHODS = {'EM_DIRICHLET': EM_DIRICHLET, 'HARD_EM_DIRICHLET': HARD_EM_DIRICHLET}
+_METHODS = {'EM_DIRICHLET': EM_DIRICHLET, 'HARD_EM_DIRICHLET': HARD_EM_DIRICHLET, 'SOFT_KMEANS': SOFT_KMEANS}
 
 
 class Evaluator_zero_shot:
@@ -63,7 +64,7 @@ class Evaluator_zero_shot:
         x_q = engine.gather_rows(table, my_idx).view(len(mine) * N, Q, K)
         y_q = labels[my_idx].view(len(mine) * N, Q)
         method = self.get_method_builder(model=model, device=self.device, args=a, log_file=self.log_file)
-        method.run_method(query=x_q, y_q=y_q.to(dev), n_batches=len(mine))
+        method.run_method(query=x_q, y_q=y_q.to(dev), n_batches=len(mine))   # SOFT_KMEANS has no cross-task coupling
         logs = method.get_logs()
         acc = torch.from_numpy(logs['acc'][:, -1].copy()).view(len(mine), N).to(dev)
         acc = sharding.gather_batch_results(acc, n_batches)
