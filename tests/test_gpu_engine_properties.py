@@ -49,6 +49,37 @@ def test_engine_equals_cpu_oracle_on_fresh_inputs(K, N, B, hard, few):
             assert (res.criterions[b].cpu().numpy() == 0).all()
 
 
+@pytest.mark.parametrize("K,Q,iter_mm,hard", [(6, 75, 30, False), (9, 75, 51, False), (11, 40, 101, True), (3, 75, 120, False),
+                                               (4, 75, 120, True), (32, 20, 150, False), (64, 75, 52, False)])
+def test_edge_shapes_and_schedules(K, Q, iter_mm, hard):
+    """Odd sizes: K below one SIMD vector (torch's scalar row sum), K a multiple of 32 (no ragged
+    register), Q != 75, iter_mm below / at / just above the first stop-test checkpoint."""
+    from oracle import c_oracle
+    from tclip_amd import engine, synth
+    N, B, iters = 3, 2, 4
+    lambd = max(1, int(K / 5)) * Q
+    x_q, _ = synth.make_query_tasks(B * N, K, seed=300 + K, n_query=Q)
+    res = engine.run_em_dirichlet(x_q.cuda(), n_batches=B, iters=iters, iter_mm=iter_mm, lambd=lambd, hard=hard)
+    torch.cuda.synchronize()
+    for b in range(B):
+        sl = slice(b * N, (b + 1) * N)
+        ref = c_oracle.run(x_q[sl].numpy(), iters=iters, iter_mm=iter_mm, lambd=lambd, hard=hard)
+        assert np.array_equal(res.mm_iters[b].cpu().numpy(), ref["mm_iters"])
+        assert np.array_equal(res.alpha[sl].cpu().numpy(), ref["alpha"])
+        assert np.array_equal(res.u[sl].cpu().numpy(), ref["u"])
+        assert np.array_equal(res.preds[sl].cpu().numpy(), ref["argmax"][-1].astype(np.int32))
+
+
+def test_argument_checks_on_device():
+    from tclip_amd import engine
+    with pytest.raises(RuntimeError, match="n_class"):
+        engine.run_em_dirichlet(torch.rand(2, 75, 1100).cuda(), n_batches=1, iters=1, lambd=75)
+    with pytest.raises(ValueError):
+        engine.run_em_dirichlet(torch.rand(3, 75, 10).cuda(), n_batches=2, iters=1, lambd=75)
+    with pytest.raises(RuntimeError, match="GPU"):
+        engine.run_em_dirichlet(torch.rand(2, 75, 10), n_batches=1, iters=1, lambd=75)
+
+
 def test_batches_are_independent_and_order_free():
     """Running batches together, separately or permuted gives bit-identical per-batch results."""
     from tclip_amd import engine, synth

@@ -860,6 +860,8 @@ static int check_problem(const tclip_problem* p) {
         p->n_support < 0)
         return fail(TCLIP_ERR_ARG, "non-positive size in tclip_problem");
     if (p->n_class < 2 || p->n_class > 1024) return fail(TCLIP_ERR_ARG, "n_class must be in 2..1024");
+    if (p->n_support > 16000) return fail(TCLIP_ERR_ARG, "n_support must be <= 16000 (member lists are staged in LDS)");
+    if ((long long)p->n_batches * p->tasks_per_batch > 65535) return fail(TCLIP_ERR_ARG, "n_batches*tasks_per_batch must be <= 65535 per call");
     if ((size_t)p->n_batches * p->tasks_per_batch * p->n_class > 0x7fffffffu)
         return fail(TCLIP_ERR_ARG, "n_batches*tasks_per_batch*n_class must fit in int32");
     return TCLIP_OK;
