@@ -107,6 +107,15 @@ size_t tclip_soft_kmeans_workspace_bytes(const tclip_problem* p);
 int tclip_soft_kmeans_run(const tclip_problem* p, const float* x_q, float temperature, float* u, float* w,
                           int32_t* preds, void* workspace, size_t workspace_bytes, void* stream);
 
+/* Probability features from visual embeddings (reference: extract_features_softmax,
+ * src/utils.py:287-290): out[n,:] = softmax_k(T * (visual[n]/||visual[n]||) . text[k]).
+ *   visual device [n_rows, dim] f32 (any norm), text device [n_class, dim] f32 (unit-norm rows, as
+ *   clip_weights returns them, src/utils.py:363-377), out device [n_rows, n_class] f32.
+ * This is the only reference-consistent way to feed visual features to EM-Dirichlet (which raises
+ * ValueError on features outside the simplex, em_dirichlet.py:204-208). */
+int tclip_probability_features(const float* visual, const float* text, int64_t n_rows, int32_t dim, int32_t n_class,
+                               float temperature, float* out, void* stream);
+
 /* Optional instrumentation used by bench.py (thread-local, off by default).  While enabled,
  * every launch of the majorize-minimize kernel issued by tclip_em_dirichlet_run on this thread is
  * bracketed by HIP events on the stream it is launched on (independent batches run on a few

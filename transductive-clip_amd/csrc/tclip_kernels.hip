@@ -352,8 +352,11 @@ __device__ __forceinline__ void mm_iterate(float (&beta)[E], const RowY<E>& yv, 
 
 constexpr int kMaxCycle = 64;  // longest limit cycle looked for on dead rows (periods up to 20 seen at K=1000)
 
+#ifndef TCLIP_MM_WAVES_SMALL
+#define TCLIP_MM_WAVES_SMALL 4     // waves per SIMD requested for short rows (E <= 8)
+#endif
 template <int E>
-__global__ __launch_bounds__(256, (E > 8 ? 3 : 4)) void k_mm_chunk(MMArgs a) {
+__global__ __launch_bounds__(256, (E > 8 ? 3 : TCLIP_MM_WAVES_SMALL)) void k_mm_chunk(MMArgs a) {
     __shared__ LogTabEntry tab[16];
     __shared__ double cyc[8][kMaxCycle][2];
     __shared__ float lg_queue[4][64 * E];             // per wave: arguments / results of the large-x lgamma
@@ -727,6 +730,64 @@ __global__ void k_gather_rows(const float* __restrict__ table, int64_t n_rows, i
     const int64_t src = idx[r];
     if (src < 0 || src >= n_rows) return;
     for (int d = threadIdx.x; d < K; d += blockDim.x) out[r * K + d] = table[src * K + d];
+}
+
+// ------------------------------------------------------------------------------------------
+// Probability-feature front-end (reference: src/utils.py:287-290): for every image embedding f,
+//   z = softmax_k( (T * f/||f||) . text_k ),  text_k unit-norm class text embeddings.
+// One block per image; the scaled embedding is staged in LDS, each thread owns classes
+// k = tid, tid+256, ... and sweeps the text matrix (K x D, L2-resident) with 16-byte loads.
+__global__ __launch_bounds__(256) void k_probability_features(const float* __restrict__ f, const float* __restrict__ text,
+                                                              int D, int K, float temperature, float* __restrict__ z) {
+    extern __shared__ float sh[];                 // D floats: scaled embedding; then K floats: logits
+    float* emb = sh;
+    float* logit = sh + D;
+    __shared__ float red[8];
+    const int n = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const float* fr = f + (size_t)n * D;
+    float ss = 0.0f;
+    for (int d = tid; d < D; d += blockDim.x) ss += fr[d] * fr[d];
+    for (int m = 32; m >= 1; m >>= 1) ss += __shfl_xor(ss, m, 64);
+    if (lane == 0) red[wave] = ss;
+    __syncthreads();
+    const float nrm = __builtin_sqrtf(red[0] + red[1] + red[2] + red[3]);
+    for (int d = tid; d < D; d += blockDim.x) emb[d] = temperature * (fr[d] / nrm);
+    __syncthreads();
+    float mx = -__builtin_inff();
+    for (int k = tid; k < K; k += blockDim.x) {
+        const float* tr = text + (size_t)k * D;
+        float acc = 0.0f;
+        int d = 0;
+        if ((D & 3) == 0) {
+            for (; d < D; d += 4) {
+                const float4 t4 = *reinterpret_cast<const float4*>(tr + d);
+                acc = __builtin_fmaf(emb[d], t4.x, acc);
+                acc = __builtin_fmaf(emb[d + 1], t4.y, acc);
+                acc = __builtin_fmaf(emb[d + 2], t4.z, acc);
+                acc = __builtin_fmaf(emb[d + 3], t4.w, acc);
+            }
+        }
+        for (; d < D; d++) acc = __builtin_fmaf(emb[d], tr[d], acc);
+        logit[k] = acc;
+        mx = acc > mx ? acc : mx;
+    }
+    for (int m = 32; m >= 1; m >>= 1) { const float o = __shfl_xor(mx, m, 64); mx = o > mx ? o : mx; }
+    __syncthreads();
+    if (lane == 0) red[4 + wave] = mx;
+    __syncthreads();
+    mx = fmaxf(fmaxf(red[4], red[5]), fmaxf(red[6], red[7]));
+    float sum = 0.0f;
+    for (int k = tid; k < K; k += blockDim.x) {
+        const float e = exp_f32_sleef(logit[k] - mx);
+        logit[k] = e;
+        sum += e;
+    }
+    for (int m = 32; m >= 1; m >>= 1) sum += __shfl_xor(sum, m, 64);
+    __syncthreads();
+    if (lane == 0) red[wave] = sum;
+    __syncthreads();
+    const float inv = 1.0f / (red[0] + red[1] + red[2] + red[3]);
+    for (int k = tid; k < K; k += blockDim.x) z[(size_t)n * K + k] = logit[k] * inv;
 }
 
 // ------------------------------------------------------------------------------------------
@@ -1182,6 +1243,18 @@ int tclip_soft_kmeans_run(const tclip_problem* pp, const float* x_q, float tempe
         hipLaunchKernelGGL(k_softmax, dim3((T * Q * 16 + 255) / 256), dim3(256), 0, st, (const float*)logit0,
                            (const float*)nullptr, T * Q, Q, K, 0.0f, 0, u, preds);
     }
+    TCLIP_HIP(hipGetLastError());
+    return TCLIP_OK;
+}
+
+int tclip_probability_features(const float* visual, const float* text, int64_t n_rows, int32_t dim, int32_t n_class,
+                               float temperature, float* out, void* stream) {
+    if (!visual || !text || !out || n_rows < 0 || dim < 1 || n_class < 1) return fail(TCLIP_ERR_ARG, "bad argument to tclip_probability_features");
+    if (n_rows == 0) return TCLIP_OK;
+    const size_t lds = ((size_t)dim + (size_t)n_class) * sizeof(float);
+    if (lds > 60000 || n_rows > 0x7fffffff) return fail(TCLIP_ERR_ARG, "dim + n_class must be <= 15000");
+    hipLaunchKernelGGL(k_probability_features, dim3((unsigned)n_rows), dim3(256), lds, (hipStream_t)stream, visual, text,
+                       dim, n_class, temperature, out);
     TCLIP_HIP(hipGetLastError());
     return TCLIP_OK;
 }
