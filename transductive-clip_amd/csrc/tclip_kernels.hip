@@ -1099,11 +1099,20 @@ struct StreamPool {
     hipStream_t s[kMaxGroups] = {};
     hipEvent_t fork = nullptr, join[kMaxGroups] = {};
     bool ready = false;
+    int device = -1;
 };
 thread_local StreamPool g_pool;
 
 static int pool_init() {
-    if (g_pool.ready) return TCLIP_OK;
+    int dev = 0;
+    TCLIP_HIP(hipGetDevice(&dev));
+    if (g_pool.ready && g_pool.device == dev) return TCLIP_OK;
+    if (g_pool.ready) {                       // the calling thread moved to another device
+        for (int i = 0; i < kMaxGroups; i++) { (void)hipStreamDestroy(g_pool.s[i]); (void)hipEventDestroy(g_pool.join[i]); }
+        (void)hipEventDestroy(g_pool.fork);
+        g_pool.ready = false;
+    }
+    g_pool.device = dev;
     for (int i = 0; i < kMaxGroups; i++) {
         TCLIP_HIP(hipStreamCreateWithFlags(&g_pool.s[i], hipStreamNonBlocking));
         TCLIP_HIP(hipEventCreateWithFlags(&g_pool.join[i], hipEventDisableTiming));
