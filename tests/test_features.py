@@ -37,3 +37,41 @@ def test_probability_features_match_formula(n, D, K, T):
     assert (z.double() - ref64).abs().max() < 2e-6
     assert (z - ref32).abs().max() < 2e-6
     assert torch.equal(z.argmax(-1), ref64.argmax(-1))
+
+
+def test_report_results_file_format(tmp_path):
+    """Row format of the reference's result files (eval_zero_shot.py:200-224, eval_few_shot.py:306-329)."""
+    from src.utils import CfgNode
+    from tclip_amd import reporting
+    a = CfgNode(shots=0, n_query=75, number_tasks=1000, k_eff=5, use_softmax_feature=True, save_results=True,
+                used_test_set="test", dataset="caltech101", name_method="EM_DIRICHLET")
+    p = reporting.report_results(a, 0.88412, 0.01, root=str(tmp_path))
+    assert p.endswith("results_zero_shot/test/caltech101/EM_DIRICHLET_softmax_0shot.txt")
+    reporting.report_results(a, 0.5, 0.01, root=str(tmp_path))
+    assert open(p).read() == "shots\tn_query\tn_task\tacc\n\t\n0\t75\t1000\t88.4\t\n0\t75\t1000\t50.0\t\n"
+    a.shots = 4
+    p = reporting.report_results(a, 0.7361, 0.01, root=str(tmp_path))
+    assert p.endswith("results_few_shot/test/caltech101/EM_DIRICHLET_softmax_s4.txt")
+    assert open(p).read() == "shots\tn_query\tk_eff\tacc\n\t\n4\t75\t5\t73.6\t\n"
+    a.save_results = False
+    assert reporting.report_results(a, 0.5, 0.01, root=str(tmp_path)) is None
+
+
+@pytest.mark.gpu
+def test_main_features_cli_matches_reference_accuracy(tmp_path):
+    """The saved-features runner on a pickle of the seeded synthetic table: the reference's mean
+    accuracy (fixture eval_zs_hard_K10) and a result file in its format."""
+    import os
+    import sys
+    from conftest import GOLDEN, PKG
+    from tclip_amd import features, synth
+    sys.path.insert(0, PKG)
+    import main_features
+    g = np.load(os.path.join(GOLDEN, "eval_zs_hard_K10.npz"))
+    feats, labels = synth.make_feature_table(int(g["K"]), int(g["rows_per_class"]), seed=int(g["seed"]))
+    plk = str(tmp_path / "test_softmax_RN50_T30.plk")
+    features.save_features(plk, feats, labels)
+    acc, t, path = main_features.main(["--query", plk, "--results-root", str(tmp_path), "--opts", "method", "hard_em_dirichlet",
+                                       "number_tasks", "20", "batch_size", "10", "dataset", "synthetic", "seed", str(int(g["seed"]))])
+    assert abs(float(acc) - float(g["mean_accuracy"])) < 1e-7
+    assert open(path).read().splitlines()[-1].split("\t")[:4] == ["0", "75", "20", str(round(100 * float(g["mean_accuracy"]), 1))]

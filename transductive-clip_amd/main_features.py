@@ -1,0 +1,108 @@
+#!/usr/bin/env python3
+"""Runs the reference's evaluation on saved feature pickles with the MI355X engine.
+
+The reference's main.py needs CLIP and the image datasets to extract features; users who already
+have the `.plk` files it writes (data/<dataset>/saved_features/<split>_softmax_<backbone>_T<T>.plk,
+src/utils.py:266-267) can run the task loop from them:
+
+    python main_features.py --query test_softmax_RN50_T30.plk [--support train_softmax_RN50_T30.plk] \\
+        --opts method em_dirichlet dataset caltech101 number_tasks 1000 batch_size 100 shots 0
+
+`--opts k v ...` follows main.py:24-33 (values are literal-eval'ed); defaults are those of
+config/main_config.yaml and config/methods_config/{em_dirichlet,hard_em_dirichlet,soft_kmeans}.yaml.
+Under `python -m torch.distributed.run --nproc-per-node N` batches are sharded over N GPUs.
+"""
+import argparse
+import os
+import random
+import sys
+from ast import literal_eval
+
+import numpy as np
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+if HERE not in sys.path:
+    sys.path.insert(0, HERE)
+
+from src.utils import CfgNode, Logger  # noqa: E402
+from tclip_amd import features, reporting  # noqa: E402
+
+MAIN_DEFAULTS = dict(dataset="synthetic", method="em_dirichlet", number_tasks=5, batch_size=5, k_eff=5, n_query=75,
+                     shots=0, log_path=".log/", save_results=True, used_test_set="test", device=0, T=30,
+                     backbone="RN50", use_softmax_feature=True, seed=2020, cuda=True)
+METHOD_DEFAULTS = {
+    "em_dirichlet": dict(name_method="EM_DIRICHLET", iter=20, iter_mm=1000, graph_matching=True, tunable=False),
+    "hard_em_dirichlet": dict(name_method="HARD_EM_DIRICHLET", iter=10, iter_mm=1000, graph_matching=True, tunable=False),
+    "soft_kmeans": dict(name_method="SOFT_KMEANS", iter=20, graph_matching=True, tunable=False),
+}
+
+
+def _decode(v):
+    try:
+        return literal_eval(v)
+    except (ValueError, SyntaxError):
+        return v
+
+
+def parse_args(argv=None):
+    ap = argparse.ArgumentParser(description=__doc__.split("\n")[0])
+    ap.add_argument("--query", required=True, help="feature pickle of the query/test split")
+    ap.add_argument("--support", default=None, help="feature pickle of the support/train split (few-shot)")
+    ap.add_argument("--results-root", default=".")
+    ap.add_argument("--opts", default=None, nargs=argparse.REMAINDER)
+    ns = ap.parse_args(argv)
+    opts = ns.opts or []
+    if len(opts) % 2:
+        ap.error("--opts takes key value pairs")
+    overrides = {opts[i]: _decode(opts[i + 1]) for i in range(0, len(opts), 2)}
+    cfg = CfgNode(MAIN_DEFAULTS)
+    cfg.update(overrides)
+    if cfg.method not in METHOD_DEFAULTS:
+        ap.error(f"method must be one of {sorted(METHOD_DEFAULTS)}")
+    cfg.update(METHOD_DEFAULTS[cfg.method])
+    cfg.update(overrides)                      # command line wins, as in main.py:32-33
+    return ns, cfg
+
+
+def main(argv=None):
+    ns, args = parse_args(argv)
+    dist_on = "RANK" in os.environ
+    local_rank = int(os.environ.get("LOCAL_RANK", args.device))
+    if args.seed is not None:                  # main.py:42-46
+        random.seed(args.seed)
+        torch.manual_seed(args.seed)
+        np.random.seed(args.seed)
+    torch.cuda.set_device(local_rank)
+    device = torch.device("cuda", local_rank)
+    if dist_on:
+        import torch.distributed as dist
+        dist.init_process_group("nccl", device_id=device)
+    feats_q, labels_q = features.load_features(ns.query)
+    args.num_classes_test = int(feats_q.shape[1]) if args.use_softmax_feature else int(labels_q.max()) + 1
+    args.n_class = args.num_classes_test
+    logger = Logger(__name__, None)
+    if int(args.shots) > 0:
+        from src.eval_few_shot import Evaluator_few_shot
+        if ns.support is None:
+            raise SystemExit("few-shot evaluation needs --support")
+        feats_s, labels_s = features.load_features(ns.support)
+        ev = Evaluator_few_shot(device=device, args=args, log_file=None)
+        acc, t = ev.evaluate_tasks(None, feats_s, labels_s, feats_q, labels_q)
+    else:
+        from src.eval_zero_shot import Evaluator_zero_shot
+        ev = Evaluator_zero_shot(device=device, args=args, log_file=None)
+        acc, t = ev.evaluate_tasks(None, feats_q, labels_q)
+    path = None
+    if acc is not None:                        # rank 0
+        path = reporting.report_results(args, acc, t, logger, root=ns.results_root)
+        print(f"mean accuracy {100 * float(acc):.2f} %  mean time/task statistic {t:.3e} s" + (f"  -> {path}" if path else ""))
+    if dist_on:
+        import torch.distributed as dist
+        dist.barrier()
+        dist.destroy_process_group()
+    return acc, t, path
+
+
+if __name__ == "__main__":
+    main()
