@@ -3,7 +3,9 @@
 cd /tmp && export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT
 TAG=${PMC_TAG:-r01}
-for set in "SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_WAVE_CYCLES SQ_BUSY_CYCLES" "SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_ANY SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_INSTS_VALU_TRANS SQ_INST_CYCLES_VMEM" "GRBM_GUI_ACTIVE SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE" "FETCH_SIZE" "WRITE_SIZE"; do
+DEFAULT_SETS="SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_WAVE_CYCLES SQ_BUSY_CYCLES|SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_ANY SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_INSTS_VALU_TRANS_F32 SQ_INST_CYCLES_VMEM_RD|GRBM_GUI_ACTIVE SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE|FETCH_SIZE|WRITE_SIZE"
+IFS='|' read -ra SETS <<< "${PMC_SETS:-$DEFAULT_SETS}"
+for set in "${SETS[@]}"; do
   tag=$(echo $set | cut -d' ' -f1)
   timeout 300 rocprofv3 --kernel-trace --pmc $set --output-format csv -d $R/gpurun_out/pmc_$tag -- python3 $R/scripts/prof_small.py "$@" > $R/gpurun_out/pmc_$tag.log 2>&1
   f=$(find $R/gpurun_out/pmc_$tag -name "*counter_collection.csv" | head -1)

@@ -23,6 +23,7 @@
 
 #include "../../include/tclip.h"
 #include "tclip_device.h"
+#include "tclip_pk.h"
 #include "tclip_selftest_inputs.h"
 
 namespace tclip {
@@ -205,17 +206,17 @@ __global__ void k_mstats(const float* __restrict__ u, const float* __restrict__ 
 }
 
 // ------------------------------------------------------------------------------------------
-// Row lists for one outer iteration.  mm_rows: rows that run the MM iteration (live rows, and dead
-// rows whose cached stop-test terms are incomplete); live_rows: rows whose alpha will change, i.e.
-// whose E-step terms must be recomputed.  Order inside the lists is irrelevant to the results.
+// Row lists for one outer iteration.  live_rows: rows whose alpha will change (k_mm_live iterates
+// them, and their E-step terms must be recomputed); dead_rows: dead rows whose cached stop-test
+// terms are incomplete (k_mm_chunk iterates them).  Order inside the lists is irrelevant to the results.
 __global__ void k_build_rows(const uint8_t* __restrict__ live, const int32_t* __restrict__ cache_len, int n_rows,
-                             int n_checks, int32_t* __restrict__ mm_rows, int32_t* __restrict__ live_rows,
-                             int32_t* __restrict__ counts /* [0]=mm, [1]=live */) {
+                             int n_checks, int32_t* __restrict__ dead_rows, int32_t* __restrict__ live_rows,
+                             int32_t* __restrict__ counts /* [0]=dead, [1]=live */) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n_rows) return;
     const bool alive = live[i];
-    const bool need = alive || (n_checks > 0 && cache_len[i] < n_checks);
-    if (need) mm_rows[atomicAdd(&counts[0], 1)] = i;
+    const bool need = !alive && n_checks > 0 && cache_len[i] < n_checks;
+    if (need) dead_rows[atomicAdd(&counts[0], 1)] = i;
     if (alive) live_rows[atomicAdd(&counts[1], 1)] = i;
 }
 
@@ -279,6 +280,60 @@ struct RowY {
     }
 };
 
+// Phase C of one MM iteration: every element's digamma, the cheap lgamma branch, the pick-up of
+// the large-argument results queued at `queue[base...]` in ballot order, and the update algebra.
+// Elements are advanced two at a time on the packed fp32 pipe (tclip_pk.h); an odd last one
+// takes the scalar form.
+#ifndef TCLIP_MM_PACKED
+#define TCLIP_MM_PACKED 1
+#endif
+template <int E>
+__device__ __forceinline__ void mm_apply_updates(float (&beta)[E], const RowY<E>& yv, int K, int lane, float psi_s,
+                                                 const LogTabEntry* tab, const float* queue, int base, bool measure,
+                                                 double& num, double& den) {
+    const unsigned long long lt_mask = (1ull << (threadIdx.x & 63)) - 1ull;
+#pragma unroll
+    for (int p = 0; p < (TCLIP_MM_PACKED ? E / 2 : 0); p++) {
+        const int e = 2 * p;
+        const f2 a{beta[e], beta[e + 1]};
+        const bool big0 = a.x + 1.0f >= 2.3f, big1 = a.y + 1.0f >= 2.3f;
+        const unsigned long long m0 = __ballot(big0);
+        const float lg0 = big0 ? queue[base + __popcll(m0 & lt_mask)] : 0.0f;
+        base += __popcll(m0);
+        const unsigned long long m1 = __ballot(big1);
+        const float lg1 = big1 ? queue[base + __popcll(m1 & lt_mask)] : 0.0f;
+        base += __popcll(m1);
+        const f2 nb = pk_mm_update(a, f2{yv.get(e), yv.get(e + 1)}, psi_s, f2{lg0, lg1}, tab);
+        const bool ok0 = e * kGroup + lane < K, ok1 = (e + 1) * kGroup + lane < K;
+        if (measure) {
+            const double d0 = (double)nb.x - (double)a.x, d1 = (double)nb.y - (double)a.y;
+            if (ok0) { num += d0 * d0; den += (double)a.x * (double)a.x; }
+            if (ok1) { num += d1 * d1; den += (double)a.y * (double)a.y; }
+        }
+        beta[e] = ok0 ? nb.x : 0.0f;
+        beta[e + 1] = ok1 ? nb.y : 0.0f;
+    }
+#pragma unroll
+    for (int e = (TCLIP_MM_PACKED ? E / 2 * 2 : 0); e < E; e++) {
+        const float a = beta[e];
+        const float x1 = a + 1.0f;
+        const bool big = x1 >= 2.3f;
+        const unsigned long long m = __ballot(big);
+        const float lg_big = big ? queue[base + __popcll(m & lt_mask)] : 0.0f;
+        base += __popcll(m);
+        const float lg_small = lgamma_sleef_05_23(big ? 2.0f : x1);
+        const float psi1 = digamma_xp1(a, tab);
+        const float nb = mm_update_algebra(a, yv.get(e), psi_s, psi1, big ? lg_big : lg_small);
+        const bool ok = e * kGroup + lane < K;
+        if (measure && ok) {
+            const double df = (double)nb - (double)a;
+            num += df * df;
+            den += (double)a * (double)a;
+        }
+        beta[e] = ok ? nb : 0.0f;
+    }
+}
+
 template <int E>
 __device__ __forceinline__ void mm_iterate(float (&beta)[E], const RowY<E>& yv, int K, int lane,
                                            const LogTabEntry* tab, float* queue, bool measure, double& num,
@@ -327,26 +382,7 @@ __device__ __forceinline__ void mm_iterate(float (&beta)[E], const RowY<E>& yv, 
     }
     __builtin_amdgcn_wave_barrier();
     // phase C: per element digamma, cheap lgamma branch, pick-up, algebra
-    int base = 0;
-#pragma unroll
-    for (int e = 0; e < E; e++) {
-        const float a = beta[e];
-        const float x1 = a + 1.0f;
-        const bool big = x1 >= 2.3f;
-        const unsigned long long m = __ballot(big);
-        const float lg_big = big ? queue[base + __popcll(m & lt_mask)] : 0.0f;
-        base += __popcll(m);
-        const float lg_small = lgamma_sleef_05_23(big ? 2.0f : x1);
-        const float psi1 = digamma_xp1(a, tab);
-        const float nb = mm_update_algebra(a, yv.get(e), psi_s, psi1, big ? lg_big : lg_small);
-        const bool ok = e * kGroup + lane < K;
-        if (measure && ok) {
-            const double df = (double)nb - (double)a;
-            num += df * df;
-            den += (double)a * (double)a;
-        }
-        beta[e] = ok ? nb : 0.0f;
-    }
+    mm_apply_updates<E>(beta, yv, K, lane, psi_s, tab, queue, 0, measure, num, den);
     __builtin_amdgcn_wave_barrier();
 }
 
@@ -442,6 +478,125 @@ __global__ __launch_bounds__(256, (E > 8 ? 3 : TCLIP_MM_WAVES_SMALL)) void k_mm_
                     c[1] = cyc[group][j][1];
                 }
                 a.cache_len[row] = a.n_checks;
+            }
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// Live rows: the same iteration, with the large-x lgamma queue shared by the whole BLOCK.
+// A wave of two rows queues only ~10-20 large arguments per iteration, so the per-wave dense pass
+// of mm_iterate still runs ~250 instructions with most lanes idle (measured: 28 % of the MM time
+// at K = 100).  Here the 8 rows of a block advance in lockstep: every wave counts its large
+// arguments, one barrier publishes the counts (and the fast-domain consensus), the waves write
+// their entries at block-wide offsets, and the dense evaluation is spread over all 256 threads.
+// Results are identical by construction: the same function is applied to the same arguments.
+template <int E>
+__device__ __forceinline__ void mm_iterate_block(float (&beta)[E], const RowY<E>& yv, int K, int lane, bool active,
+                                                 const LogTabEntry* tab, float* queue, int* wave_cnt, int turn,
+                                                 bool measure, double& num, double& den) {
+    const int wave = threadIdx.x >> 6, lane64 = threadIdx.x & 63;
+    float s = 16.0f;
+    bool in_domain = true;
+    if (active) {
+        s = group_sum_torch<E>(beta, K, lane);
+        in_domain = fast_range_f32(s) && s <= 0x1p40f;
+#pragma unroll
+        for (int e = 0; e < E; e++) in_domain = in_domain && mm_fast_domain(beta[e]);
+    }
+    int n_wave = 0;
+#pragma unroll
+    for (int e = 0; e < E; e++) n_wave += __popcll(__ballot(active && beta[e] + 1.0f >= 2.3f));
+    if (lane64 == 0) wave_cnt[wave] = n_wave;
+    if (__builtin_expect(!__syncthreads_and(in_domain), 0)) {   // NaN / inf / out of range somewhere in the block
+        if (active) {
+            const float psi_s = digamma_f32(s);
+#pragma unroll
+            for (int e = 0; e < E; e++) {
+                const float nb = mm_update_generic(beta[e], yv.get(e), psi_s);
+                const bool ok = e * kGroup + lane < K;
+                if (measure && ok) {
+                    const double df = (double)nb - (double)beta[e];
+                    num += df * df;
+                    den += (double)beta[e] * (double)beta[e];
+                }
+                beta[e] = ok ? nb : 0.0f;
+            }
+        }
+        __syncthreads();                                        // wave_cnt is rewritten next iteration
+        return;
+    }
+    const int c0 = wave_cnt[0], c1 = wave_cnt[1], c2 = wave_cnt[2], c3 = wave_cnt[3];
+    const int wave_base = wave == 0 ? 0 : wave == 1 ? c0 : wave == 2 ? c0 + c1 : c0 + c1 + c2;
+    const int n_big = c0 + c1 + c2 + c3;
+    const unsigned long long lt_mask = (1ull << lane64) - 1ull;
+    // phase A: queue the arguments of the expensive lgamma branch
+    int idx = wave_base;
+#pragma unroll
+    for (int e = 0; e < E; e++) {
+        const float x1 = beta[e] + 1.0f;
+        const bool big = active && x1 >= 2.3f;
+        const unsigned long long m = __ballot(big);
+        if (big) queue[idx + __popcll(m & lt_mask)] = x1;
+        idx += __popcll(m);
+    }
+    __syncthreads();
+    // phase B: dense evaluation, results overwrite the queue.  Usually one pass of one wave covers
+    // the whole queue; the wave that takes the first 64 entries rotates with the iteration so that
+    // this work spreads over the four SIMDs of the CU (wave w of every block sits on SIMD w).
+    for (int start = ((wave + turn) & 3) * 64; start < n_big; start += 256) {
+        const int j = start + lane64;
+        const float v = j < n_big ? queue[j] : 8.0f;
+        const float r = lgamma_sleef_ge23<true>(v);
+        if (j < n_big) queue[j] = r;
+    }
+    const float psi_s = digamma_pos_f32(s, tab);
+    __syncthreads();
+    // phase C: per element digamma, cheap lgamma branch, pick-up, algebra
+    if (!active) return;
+    mm_apply_updates<E>(beta, yv, K, lane, psi_s, tab, queue, wave_base, measure, num, den);
+}
+
+template <int E>
+__global__ __launch_bounds__(256, (E > 8 ? 3 : TCLIP_MM_WAVES_SMALL)) void k_mm_live(MMArgs a) {
+    __shared__ LogTabEntry tab[16];
+    __shared__ float queue[256 * E];
+    __shared__ int wave_cnt[4];
+    load_log_table(tab);
+    const int lane = threadIdx.x & (kGroup - 1);
+    const int group = threadIdx.x / kGroup;
+    constexpr int kRows = 256 / kGroup;
+    const int n = *a.n_rows;
+    const int K = a.K;
+    for (int first = blockIdx.x * kRows; first < n; first += gridDim.x * kRows) {   // block-uniform trip count
+        const int i = first + group;
+        const int row = i < n ? a.rows[i] : 0;
+        const bool active = i < n && !a.stop[row / a.rows_per_batch];
+        float beta[E];
+        RowY<E> yv;
+        yv.load(a.y + (size_t)row * K, lane, K);
+#pragma unroll
+        for (int e = 0; e < E; e++) {
+            const int d = e * kGroup + lane;
+            beta[e] = (active && d < K) ? a.alpha[(size_t)row * K + d] : 0.0f;
+        }
+        double num = 0.0, den = 0.0;
+        for (int l = a.l0; l <= a.l1; l++)
+            mm_iterate_block<E>(beta, yv, K, lane, active, tab, queue, wave_cnt, l, a.has_check && l == a.l1, num, den);
+        if (!active) continue;
+#pragma unroll
+        for (int e = 0; e < E; e++) {
+            const int d = e * kGroup + lane;
+            if (d < K) a.alpha[(size_t)row * K + d] = beta[e];
+        }
+        if (a.work_counter && lane == 0)
+            atomicAdd(a.work_counter, (unsigned long long)K * (unsigned long long)(a.l1 - a.l0 + 1));
+        if (a.has_check) {
+            num = group_sum_f64(num);
+            den = group_sum_f64(den);
+            if (lane == 0) {
+                a.rowpart[2 * (size_t)row] = num;
+                a.rowpart[2 * (size_t)row + 1] = den;
             }
         }
     }
@@ -831,6 +986,19 @@ __global__ void k_selftest(unsigned long long* out) {
         const bool differ = !(uf == ug || (uf != uf && ug != ug));    // both NaN (0/0 after exact cancellation) is agreement
         b4 += differ;
         if (differ) { out[14] = f32_bits(a); out[15] = f32_bits(y); out[16] = f32_bits(ps); out[17] = f32_bits(uf); out[18] = f32_bits(ug); }
+        // the packed form, on (a, a second argument concentrated on 2^-12 .. 2^6)
+        const float a2 = rand_float(i, 4u, -12, 18);
+        const f2 av{a, a2};
+        const f2 lgb{a + 1.0f >= 2.3f ? lgamma_sleef_ge23<true>(a + 1.0f) : 0.0f,
+                     a2 + 1.0f >= 2.3f ? lgamma_sleef_ge23<true>(a2 + 1.0f) : 0.0f};
+        const f2 up = pk_mm_update(av, f2{y, y}, ps, lgb, tab);
+        const float ug2 = mm_update_generic(a2, y, ps);
+        const bool differ0 = !(up.x == ug || (up.x != up.x && ug != ug));
+        const bool differ1 = !(up.y == ug2 || (up.y != up.y && ug2 != ug2));
+        b4 += differ0;
+        b4 += differ1;
+        if (differ0) { out[14] = f32_bits(a); out[15] = f32_bits(y); out[16] = f32_bits(ps); out[17] = f32_bits(up.x); out[18] = f32_bits(ug); }
+        if (differ1) { out[14] = f32_bits(a2); out[15] = f32_bits(y); out[16] = f32_bits(ps); out[17] = f32_bits(up.y); out[18] = f32_bits(ug2); }
     }
     atomicAdd(&out[0], b0); atomicAdd(&out[1], b1); atomicAdd(&out[2], b2);
     atomicAdd(&out[3], b3); atomicAdd(&out[4], b4); atomicAdd(&out[5], b5);
@@ -949,6 +1117,9 @@ static void dispatch_E(int K, Args... args) {
 template <int E> struct LaunchMM {
     static void run(int grid, hipStream_t st, MMArgs a) { hipLaunchKernelGGL(k_mm_chunk<E>, dim3(grid), dim3(256), 0, st, a); }
 };
+template <int E> struct LaunchMMLive {
+    static void run(int grid, hipStream_t st, MMArgs a) { hipLaunchKernelGGL(k_mm_live<E>, dim3(grid), dim3(256), 0, st, a); }
+};
 template <int E> struct LaunchRowConsts {
     static void run(int grid, hipStream_t st, const float* alpha, const int32_t* rows, const int32_t* n, int K, float* rowc) {
         hipLaunchKernelGGL(k_row_consts<E>, dim3(grid), dim3(256), 0, st, alpha, rows, n, K, rowc);
@@ -1066,7 +1237,12 @@ static int enqueue_batches(const tclip_problem& p, const float* x_q, const float
             if (grid > 256 * 16) grid = 256 * 16;
             hipEvent_t e0 = g_prof.on ? prof_event() : nullptr, e1 = g_prof.on ? prof_event() : nullptr;
             if (e0 && e1) TCLIP_HIP(hipEventRecord(e0, st));
-            dispatch_E<LaunchMM>(K, grid, st, a);
+            a.rows = live_rows; a.n_rows = counts + 1;
+            dispatch_E<LaunchMMLive>(K, grid, st, a);
+            if (zs && a.has_check) {          // dead rows only matter through their stop-test terms
+                a.rows = mm_rows; a.n_rows = counts;
+                dispatch_E<LaunchMM>(K, grid, st, a);
+            }
             if (e0 && e1) TCLIP_HIP(hipEventRecord(e1, st));
             hipLaunchKernelGGL(k_mm_decide, dim3(B), dim3(1024), 0, st, (const double*)rowpart, (const double*)cache,
                                (const uint8_t*)live, N * K, a.n_checks, c, a.has_check, a.l1, c == n_chunks - 1 ? 1 : 0,

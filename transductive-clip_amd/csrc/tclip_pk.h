@@ -1,0 +1,132 @@
+// Two-wide forms of the MM update's arithmetic for gfx950's packed fp32 pipe.
+//
+// One lane owns elements d, d+32, d+64, ... of a row; two of them are advanced together so that
+// every add / multiply / fma of the restated library routines issues as ONE v_pk_{add,mul,fma}_f32
+// (IEEE-rounded per component, exactly the scalar instruction's result) instead of two scalar
+// instructions.  What cannot be packed stays per component: v_rcp_f32, the table look-ups of
+// logf and of the VRSQRT14 emulation, the fp64 tail of logf, selects.
+//
+// Every function here is the component-wise image of the scalar function of the same name in
+// tclip_math.h / tclip_device.h (same operations, same order, contraction off), valid on the
+// same fast domain 0 <= a <= 2^40; k_selftest compares the two bit for bit on 2^24 arguments.
+// Device only.
+#pragma once
+#include "tclip_math.h"
+
+namespace tclip {
+
+typedef float f2 __attribute__((ext_vector_type(2)));
+typedef int i2 __attribute__((ext_vector_type(2)));
+
+__device__ __forceinline__ f2 pk(float v) { return f2{v, v}; }
+__device__ __forceinline__ f2 pk_fma(f2 a, f2 b, f2 c) { return __builtin_elementwise_fma(a, b, c); }
+__device__ __forceinline__ f2 pk_sel(i2 m, f2 a, f2 b) { return m ? a : b; }
+__device__ __forceinline__ f2 pk_sel(i2 m, float a, float b) { return m ? pk(a) : pk(b); }
+
+// RN(1/x), see rcp_rn_f32
+__device__ __forceinline__ f2 pk_rcp_rn(f2 x) {
+    f2 r{__builtin_amdgcn_rcpf(x.x), __builtin_amdgcn_rcpf(x.y)};
+    const f2 e = pk_fma(-x, r, pk(1.0f));
+    return pk_fma(e, r, r);
+}
+
+// RN(a/b), see div_rn_inrange_f32
+__device__ __forceinline__ f2 pk_div_rn(f2 a, f2 b) {
+    const f2 r = pk_rcp_rn(b);
+    const f2 q = a * r;
+    const f2 rem = pk_fma(-b, q, a);
+    return pk_fma(rem, r, q);
+}
+
+// digamma(a+1), see digamma_xp1.  The step mask is a float: acc - m*RN(1/x) and x + m round
+// once, exactly as the scalar's conditional updates (m*r is exact for m in {0,1}).
+__device__ __forceinline__ f2 pk_digamma_xp1(f2 a, const LogTabEntry* tab) {
+    f2 x = a + pk(1.0f), acc = pk(0.0f);
+#pragma unroll
+    for (int j = 0; j < 9; j++) {
+        const f2 m{below10_f32(x.x), below10_f32(x.y)};
+        const f2 r = pk_rcp_rn(x);
+        acc = pk_fma(-m, r, acc);
+        x = x + m;
+    }
+    const f2 z = pk_rcp_rn(x * x);
+    f2 p = pk(8.33333333333333333333E-2f);
+    p = pk_fma(p, z, pk(-2.10927960927960927961E-2f));
+    p = pk_fma(p, z, pk(7.57575757575757575758E-3f));
+    p = pk_fma(p, z, pk(-4.16666666666666666667E-3f));
+    p = pk_fma(p, z, pk(3.96825396825396825397E-3f));
+    p = pk_fma(p, z, pk(-8.33333333333333333333E-3f));
+    p = pk_fma(p, z, pk(8.33333333333333333333E-2f));
+    const f2 y = z * p;
+    const f2 lg{logf_glibc_tab(x.x, tab), logf_glibc_tab(x.y, tab)};
+    const f2 series = ((acc + lg) - pk(0.5f) * pk_rcp_rn(x)) - y;
+    return pk_sel(x == pk(10.0f), acc + pk(2.25175258906672110764f), series);
+}
+
+// double-float helpers, see the df_* functions
+struct P2 { f2 x, y; };
+__device__ __forceinline__ P2 pk_df_add2_f2_f(P2 a, f2 b) {
+    const f2 s = a.x + b, v = s - a.x;
+    const f2 t = (a.x - (s - v)) + (b - v);
+    return P2{s, t + a.y};
+}
+__device__ __forceinline__ P2 pk_df_mul_f_f(f2 a, f2 b) {
+    const f2 s = a * b;
+    return P2{s, pk_fma(a, b, -s)};
+}
+__device__ __forceinline__ P2 pk_df_mul_f2_f(P2 a, f2 b) {
+    const f2 s = a.x * b;
+    return P2{s, pk_fma(a.y, b, pk_fma(a.x, b, -s))};
+}
+
+// lgamma on [0.5, 2.3), see lgamma_sleef_05_23 / sleef_lgamma_poly
+__device__ __forceinline__ f2 pk_lgamma_sleef_05_23(f2 x) {
+    const i2 o0 = x <= pk(1.2f);
+    const P2 d = pk_df_add2_f2_f(P2{x, pk(0.0f)}, pk_sel(o0, -1.0f, -2.0f));
+    const f2 t = d.x + d.y;
+    f2 u = pk_sel(o0, +0.9435157776e+0f, +0.1102489550e-3f);
+    u = pk_fma(u, t, pk_sel(o0, +0.8670063615e+0f, +0.8160019934e-4f));
+    u = pk_fma(u, t, pk_sel(o0, +0.4826702476e+0f, +0.1528468856e-3f));
+    u = pk_fma(u, t, pk_sel(o0, -0.8855129778e-1f, -0.2355068718e-3f));
+    u = pk_fma(u, t, pk_sel(o0, +0.1013825238e+0f, +0.4962242092e-3f));
+    u = pk_fma(u, t, pk_sel(o0, -0.1493408978e+0f, -0.1193488017e-2f));
+    u = pk_fma(u, t, pk_sel(o0, +0.1697509140e+0f, +0.2891599433e-2f));
+    u = pk_fma(u, t, pk_sel(o0, -0.2072454542e+0f, -0.7385451812e-2f));
+    u = pk_fma(u, t, pk_sel(o0, +0.2705872357e+0f, +0.2058077045e-1f));
+    P2 z = pk_df_add2_f2_f(pk_df_mul_f_f(u, t), pk_sel(o0, -0.400686534596170958447352690395e+0f, -0.673523028297382446749257758235e-1f));
+    z = pk_df_add2_f2_f(pk_df_mul_f2_f(z, t), pk_sel(o0, +0.822466960142643054450325495997e+0f, +0.322467033928981157743538726901e+0f));
+    z = pk_df_add2_f2_f(pk_df_mul_f2_f(z, t), pk_sel(o0, -0.577215665946766039837398973297e+0f, +0.422784335087484338986941629852e+0f));
+    z = pk_df_mul_f2_f(z, t);
+    return z.x + z.y;
+}
+
+// torch.sqrt, see sqrt_torch_inrange_f32
+__device__ __forceinline__ f2 pk_sqrt_torch_inrange(f2 x) {
+    const f2 y{rsqrt14_f32(x.x), rsqrt14_f32(x.y)};
+    const f2 s = x * y;
+    return pk_fma(pk_fma(-s, s, x), pk(0.5f) * y, s);
+}
+
+// One MM update of two parameters, see mm_update_algebra.
+__device__ __forceinline__ f2 pk_mm_update_algebra(f2 a, f2 y, float psi_s, f2 psi1, f2 lg1) {
+    const f2 t = (pk(0.0f) - lg1) + psi1 * a;
+    const f2 big = __builtin_elementwise_abs(pk_div_rn(pk(2.0f) * t, a * a));
+    const f2 curv = pk_sel(a > pk(1e-11f), big, pk(1.6449340668482264f));
+    f2 b = (psi1 - pk(psi_s)) - curv * a;
+    b = b - y;
+    const f2 delta = b * b + pk(4.0f) * curv;
+    const f2 nume = -b + pk_sqrt_torch_inrange(delta), deno = pk(2.0f) * curv;
+    return pk_sel(deno == pk(0.0f), nume * pk(__builtin_inff()), pk_div_rn(nume, deno));
+}
+
+// lg1 = lgamma(a+1): the caller supplies the large-argument results (a+1 >= 2.3) it evaluated
+// elsewhere; the polynomial branch is computed here for the rest.
+__device__ __forceinline__ f2 pk_mm_update(f2 a, f2 y, float psi_s, f2 lg_big, const LogTabEntry* tab) {
+    const f2 x1 = a + pk(1.0f);
+    const i2 big = x1 >= pk(2.3f);
+    const f2 lg_small = pk_lgamma_sleef_05_23(pk_sel(big, pk(2.0f), x1));
+    const f2 psi1 = pk_digamma_xp1(a, tab);
+    return pk_mm_update_algebra(a, y, psi_s, psi1, pk_sel(big, lg_big, lg_small));
+}
+
+}  // namespace tclip
