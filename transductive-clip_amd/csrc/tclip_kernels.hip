@@ -4,9 +4,11 @@
 // Stream of one outer iteration (reference: src/methods/zero_shot/em_dirichlet.py:214-244):
 //   k_cluster_sizes   cs = sum_q u, live mask, v                                   (:217-218, :151)
 //   k_mstats          y = u^T log z / cs  (+ support statistics in few-shot)       (:219-222)
-//   k_build_rows      compact the rows that must iterate: live rows + dead rows whose stop-test
+//   k_build_rows      compact the rows that must iterate: live rows; dead rows whose stop-test
 //                     contributions are not cached yet
-//   k_mm_chunk x20    <=50 majorize-minimize iterations per launch, alpha rows register-resident,
+//   k_mm_live x20     <=50 majorize-minimize iterations per launch for the live rows, alpha rows
+//                     register-resident, large-argument lgamma work queued block-wide in LDS
+//   k_mm_chunk x20    the same for the listed dead rows (per-wave queue, limit-cycle detection)
 //   k_mm_decide x20   batch-global stop test on device, no host round trip          (:157-177)
 //   k_row_consts      lgamma(sum alpha) - sum lgamma(alpha) for rows that changed  (:35-36)
 //   k_logits          (alpha-1) . log z contraction for rows that changed          (:37-38)
@@ -303,7 +305,7 @@ __device__ __forceinline__ void mm_apply_updates(float (&beta)[E], const RowY<E>
         const unsigned long long m1 = __ballot(big1);
         const float lg1 = big1 ? queue[base + __popcll(m1 & lt_mask)] : 0.0f;
         base += __popcll(m1);
-        const f2 nb = pk_mm_update(a, f2{yv.get(e), yv.get(e + 1)}, psi_s, f2{lg0, lg1}, tab);
+        const f2 nb = pk_mm_update(a, f2{yv.get(e), yv.get(e + 1)}, pk(psi_s), f2{lg0, lg1}, tab);
         const bool ok0 = e * kGroup + lane < K, ok1 = (e + 1) * kGroup + lane < K;
         if (measure) {
             const double d0 = (double)nb.x - (double)a.x, d1 = (double)nb.y - (double)a.y;
@@ -491,11 +493,19 @@ __global__ __launch_bounds__(256, (E > 8 ? 3 : TCLIP_MM_WAVES_SMALL)) void k_mm_
 // arguments, one barrier publishes the counts (and the fast-domain consensus), the waves write
 // their entries at block-wide offsets, and the dense evaluation is spread over all 256 threads.
 // Results are identical by construction: the same function is applied to the same arguments.
+// Block-wide queue bookkeeping in LDS.  Every wave fills its own slice of the queue and posts its
+// entry count for this iteration (count[turn & 1][wave]) before the single barrier that publishes
+// both; counts are double-buffered and slices are wave-private outside the dense pass, so a wave
+// that runs ahead into the next iteration cannot disturb one that is still picking up results.
+// `bad` is raised by a wave that holds an argument outside the fast domain.
+struct QueueCtl { int count[2][4]; int bad; };
+
 template <int E>
 __device__ __forceinline__ void mm_iterate_block(float (&beta)[E], const RowY<E>& yv, int K, int lane, bool active,
-                                                 const LogTabEntry* tab, float* queue, int* wave_cnt, int turn,
+                                                 const LogTabEntry* tab, float* queue, QueueCtl* ctl, int turn,
                                                  bool measure, double& num, double& den) {
     const int wave = threadIdx.x >> 6, lane64 = threadIdx.x & 63;
+    const unsigned long long lt_mask = (1ull << lane64) - 1ull;
     float s = 16.0f;
     bool in_domain = true;
     if (active) {
@@ -504,11 +514,32 @@ __device__ __forceinline__ void mm_iterate_block(float (&beta)[E], const RowY<E>
 #pragma unroll
         for (int e = 0; e < E; e++) in_domain = in_domain && mm_fast_domain(beta[e]);
     }
+    // phase A: queue the arguments of the expensive lgamma branch
     int n_wave = 0;
 #pragma unroll
     for (int e = 0; e < E; e++) n_wave += __popcll(__ballot(active && beta[e] + 1.0f >= 2.3f));
-    if (lane64 == 0) wave_cnt[wave] = n_wave;
-    if (__builtin_expect(!__syncthreads_and(in_domain), 0)) {   // NaN / inf / out of range somewhere in the block
+    const bool wave_ok = __all(in_domain);
+    if (lane64 == 0) {
+        ctl->count[turn & 1][wave] = n_wave;
+        if (!wave_ok) ctl->bad = 1;
+    }
+    float* slice = queue + wave * (64 * E);
+    int idx = 0;
+#pragma unroll
+    for (int e = 0; e < E; e++) {
+        const float x1 = beta[e] + 1.0f;
+        const bool big = active && x1 >= 2.3f;
+        const unsigned long long m = __ballot(big);
+        if (big) slice[idx + __popcll(m & lt_mask)] = x1;
+        idx += __popcll(m);
+    }
+    __syncthreads();
+    const int c0 = ctl->count[turn & 1][0], c1 = ctl->count[turn & 1][1], c2 = ctl->count[turn & 1][2];
+    const int n_big = c0 + c1 + c2 + ctl->count[turn & 1][3];
+    const bool bad = ctl->bad != 0;
+    if (__builtin_expect(bad, 0)) {                             // NaN / inf / out of range somewhere in the block
+        __syncthreads();                                        // everyone has seen the flag
+        if (threadIdx.x == 0) ctl->bad = 0;
         if (active) {
             const float psi_s = digamma_f32(s);
 #pragma unroll
@@ -523,55 +554,45 @@ __device__ __forceinline__ void mm_iterate_block(float (&beta)[E], const RowY<E>
                 beta[e] = ok ? nb : 0.0f;
             }
         }
-        __syncthreads();                                        // wave_cnt is rewritten next iteration
+        __syncthreads();
         return;
     }
-    const int c0 = wave_cnt[0], c1 = wave_cnt[1], c2 = wave_cnt[2], c3 = wave_cnt[3];
-    const int wave_base = wave == 0 ? 0 : wave == 1 ? c0 : wave == 2 ? c0 + c1 : c0 + c1 + c2;
-    const int n_big = c0 + c1 + c2 + c3;
-    const unsigned long long lt_mask = (1ull << lane64) - 1ull;
-    // phase A: queue the arguments of the expensive lgamma branch
-    int idx = wave_base;
-#pragma unroll
-    for (int e = 0; e < E; e++) {
-        const float x1 = beta[e] + 1.0f;
-        const bool big = active && x1 >= 2.3f;
-        const unsigned long long m = __ballot(big);
-        if (big) queue[idx + __popcll(m & lt_mask)] = x1;
-        idx += __popcll(m);
-    }
-    __syncthreads();
     // phase B: dense evaluation, results overwrite the queue.  Usually one pass of one wave covers
     // the whole queue; the wave that takes the first 64 entries rotates with the iteration so that
     // this work spreads over the four SIMDs of the CU (wave w of every block sits on SIMD w).
     for (int start = ((wave + turn) & 3) * 64; start < n_big; start += 256) {
-        const int j = start + lane64;
-        const float v = j < n_big ? queue[j] : 8.0f;
+        const int j = start + lane64;                          // j-th entry of the block, slices in wave order
+        const int w = (j >= c0) + (j >= c0 + c1) + (j >= c0 + c1 + c2);
+        const int at = w * (64 * E) + j - (w == 0 ? 0 : w == 1 ? c0 : w == 2 ? c0 + c1 : c0 + c1 + c2);
+        const float v = j < n_big ? queue[at] : 8.0f;
         const float r = lgamma_sleef_ge23<true>(v);
-        if (j < n_big) queue[j] = r;
+        if (j < n_big) queue[at] = r;
     }
     const float psi_s = digamma_pos_f32(s, tab);
     __syncthreads();
     // phase C: per element digamma, cheap lgamma branch, pick-up, algebra
     if (!active) return;
-    mm_apply_updates<E>(beta, yv, K, lane, psi_s, tab, queue, wave_base, measure, num, den);
+    mm_apply_updates<E>(beta, yv, K, lane, psi_s, tab, slice, 0, measure, num, den);
 }
 
 template <int E>
 __global__ __launch_bounds__(256, (E > 8 ? 3 : TCLIP_MM_WAVES_SMALL)) void k_mm_live(MMArgs a) {
     __shared__ LogTabEntry tab[16];
     __shared__ float queue[256 * E];
-    __shared__ int wave_cnt[4];
+    __shared__ QueueCtl ctl;
+    if (threadIdx.x == 0) ctl.bad = 0;
     load_log_table(tab);
     const int lane = threadIdx.x & (kGroup - 1);
     const int group = threadIdx.x / kGroup;
     constexpr int kRows = 256 / kGroup;
+    int turn = 0;
     const int n = *a.n_rows;
     const int K = a.K;
     for (int first = blockIdx.x * kRows; first < n; first += gridDim.x * kRows) {   // block-uniform trip count
         const int i = first + group;
         const int row = i < n ? a.rows[i] : 0;
         const bool active = i < n && !a.stop[row / a.rows_per_batch];
+        if (!__syncthreads_or(active)) continue;                 // e.g. every batch of these rows has stopped
         float beta[E];
         RowY<E> yv;
         yv.load(a.y + (size_t)row * K, lane, K);
@@ -582,7 +603,7 @@ __global__ __launch_bounds__(256, (E > 8 ? 3 : TCLIP_MM_WAVES_SMALL)) void k_mm_
         }
         double num = 0.0, den = 0.0;
         for (int l = a.l0; l <= a.l1; l++)
-            mm_iterate_block<E>(beta, yv, K, lane, active, tab, queue, wave_cnt, l, a.has_check && l == a.l1, num, den);
+            mm_iterate_block<E>(beta, yv, K, lane, active, tab, queue, &ctl, turn++, a.has_check && l == a.l1, num, den);
         if (!active) continue;
 #pragma unroll
         for (int e = 0; e < E; e++) {
@@ -991,7 +1012,7 @@ __global__ void k_selftest(unsigned long long* out) {
         const f2 av{a, a2};
         const f2 lgb{a + 1.0f >= 2.3f ? lgamma_sleef_ge23<true>(a + 1.0f) : 0.0f,
                      a2 + 1.0f >= 2.3f ? lgamma_sleef_ge23<true>(a2 + 1.0f) : 0.0f};
-        const f2 up = pk_mm_update(av, f2{y, y}, ps, lgb, tab);
+        const f2 up = pk_mm_update(av, f2{y, y}, pk(ps), lgb, tab);
         const float ug2 = mm_update_generic(a2, y, ps);
         const bool differ0 = !(up.x == ug || (up.x != up.x && ug != ug));
         const bool differ1 = !(up.y == ug2 || (up.y != up.y && ug2 != ug2));

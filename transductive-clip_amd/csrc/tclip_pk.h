@@ -107,12 +107,12 @@ __device__ __forceinline__ f2 pk_sqrt_torch_inrange(f2 x) {
     return pk_fma(pk_fma(-s, s, x), pk(0.5f) * y, s);
 }
 
-// One MM update of two parameters, see mm_update_algebra.
-__device__ __forceinline__ f2 pk_mm_update_algebra(f2 a, f2 y, float psi_s, f2 psi1, f2 lg1) {
+// One MM update of two parameters (psi_s: digamma of the row sum of each one's row), see mm_update_algebra.
+__device__ __forceinline__ f2 pk_mm_update_algebra(f2 a, f2 y, f2 psi_s, f2 psi1, f2 lg1) {
     const f2 t = (pk(0.0f) - lg1) + psi1 * a;
     const f2 big = __builtin_elementwise_abs(pk_div_rn(pk(2.0f) * t, a * a));
     const f2 curv = pk_sel(a > pk(1e-11f), big, pk(1.6449340668482264f));
-    f2 b = (psi1 - pk(psi_s)) - curv * a;
+    f2 b = (psi1 - psi_s) - curv * a;
     b = b - y;
     const f2 delta = b * b + pk(4.0f) * curv;
     const f2 nume = -b + pk_sqrt_torch_inrange(delta), deno = pk(2.0f) * curv;
@@ -121,7 +121,7 @@ __device__ __forceinline__ f2 pk_mm_update_algebra(f2 a, f2 y, float psi_s, f2 p
 
 // lg1 = lgamma(a+1): the caller supplies the large-argument results (a+1 >= 2.3) it evaluated
 // elsewhere; the polynomial branch is computed here for the rest.
-__device__ __forceinline__ f2 pk_mm_update(f2 a, f2 y, float psi_s, f2 lg_big, const LogTabEntry* tab) {
+__device__ __forceinline__ f2 pk_mm_update(f2 a, f2 y, f2 psi_s, f2 lg_big, const LogTabEntry* tab) {
     const f2 x1 = a + pk(1.0f);
     const i2 big = x1 >= pk(2.3f);
     const f2 lg_small = pk_lgamma_sleef_05_23(pk_sel(big, pk(2.0f), x1));
