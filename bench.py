@@ -12,7 +12,7 @@ for N>1 by the single RCCL gather of the per-task predictions.  Weak scaling: ev
 own 1000 tasks (independent batches, no data-path collective).
 
 Extra objects on the JSON line:
-  roofline     the dominant kernel k_mm_chunk, timed live with HIP events around each of its
+  roofline     the dominant kernel k_mm_live (+ its dead-row twin k_mm_chunk), timed live with HIP events around each of its
                launches on the streams they run on (independent batches use a few internal
                streams, so launches overlap: `achieved` divides by the time during which at least
                one launch was running, `avg_launch_ms` is the plain mean launch duration).  The path is fp32 vector-ALU bound, so the bound is
@@ -158,7 +158,7 @@ def main():
                        "n_class": K_CLASSES, "n_query": N_QUERY, "tasks_per_batch": TASKS_PER_BATCH,
                        "batches_per_gpu": N_BATCHES, "parallelism": f"batch-sharded x{world}",
                        "mean_accuracy": float(acc.mean()), "mm_iters_batch0": mm_iters[0].tolist()},
-            "roofline": {"bound": "valu", "kernel": "k_mm_chunk", "achieved": achieved, "peak": PEAK_VALU_TFLOPS,
+            "roofline": {"bound": "valu", "kernel": "k_mm_live", "achieved": achieved, "peak": PEAK_VALU_TFLOPS,
                          "unit": "TFLOP/s", "frac": achieved / PEAK_VALU_TFLOPS, "traffic": None,
                          "flop_eq_per_element_update": FLOP_EQ_PER_UPDATE,
                          "element_updates_executed_per_step": updates / steps,

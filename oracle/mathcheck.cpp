@@ -19,6 +19,20 @@ MC_MAP(mc_sqrt_torch, tclip::sqrt_torch_f32(v))
 MC_MAP(mc_lgamma_cr, (float)lgamma((double)v))
 void mc_xp1_psi(const float* x, float* y, long n) { for (long i = 0; i < n; i++) { float p, l; tclip::digamma_lgamma_xp1(x[i], tclip::kLogTab, p, l); y[i] = p; } }
 void mc_xp1_lg(const float* x, float* y, long n) { for (long i = 0; i < n; i++) { float p, l; tclip::digamma_lgamma_xp1(x[i], tclip::kLogTab, p, l); y[i] = l; } }
+// every float of [1, 2.3): out[0] = arguments where the fp64 form of lgamma is sure and differs from the
+// double-float form (must be 0), out[1] = arguments it is unsure about, out[2] = arguments visited
+void mc_lgamma_f64_form(unsigned long long* out) {
+    out[0] = out[1] = out[2] = 0;
+    for (uint32_t b = tclip::f32_bits(1.0f); b < tclip::f32_bits(2.3f); b++) {
+        const float x = tclip::bits_f32(b);
+        bool sure;
+        const float fast = tclip::lgamma_sleef_1_23_f64(x, sure);
+        const float ref = tclip::lgamma_sleef_05_23(x);
+        out[2]++;
+        if (!sure) out[1]++;
+        else if (tclip::f32_bits(fast) != tclip::f32_bits(ref)) out[0]++;
+    }
+}
 // checksums of the routines over the self-test's argument streams (see tclip_selftest_inputs.h)
 void mc_checksums(unsigned long long* out) {
     for (int f = 0; f < tclip::kSelfTestFunctions; f++) out[f] = 0;

@@ -323,7 +323,9 @@ __device__ __forceinline__ void mm_apply_updates(float (&beta)[E], const RowY<E>
         const unsigned long long m = __ballot(big);
         const float lg_big = big ? queue[base + __popcll(m & lt_mask)] : 0.0f;
         base += __popcll(m);
-        const float lg_small = lgamma_sleef_05_23(big ? 2.0f : x1);
+        bool sure;
+        float lg_small = lgamma_sleef_1_23_f64(big ? 2.0f : x1, sure);
+        if (__builtin_expect(__ballot(!sure) != 0ull, 0)) lg_small = sure ? lg_small : lgamma_sleef_05_23(big ? 2.0f : x1);
         const float psi1 = digamma_xp1(a, tab);
         const float nb = mm_update_algebra(a, yv.get(e), psi_s, psi1, big ? lg_big : lg_small);
         const bool ok = e * kGroup + lane < K;
@@ -514,15 +516,7 @@ __device__ __forceinline__ void mm_iterate_block(float (&beta)[E], const RowY<E>
 #pragma unroll
         for (int e = 0; e < E; e++) in_domain = in_domain && mm_fast_domain(beta[e]);
     }
-    // phase A: queue the arguments of the expensive lgamma branch
-    int n_wave = 0;
-#pragma unroll
-    for (int e = 0; e < E; e++) n_wave += __popcll(__ballot(active && beta[e] + 1.0f >= 2.3f));
-    const bool wave_ok = __all(in_domain);
-    if (lane64 == 0) {
-        ctl->count[turn & 1][wave] = n_wave;
-        if (!wave_ok) ctl->bad = 1;
-    }
+    // phase A: queue the arguments of the expensive lgamma branch in this wave's slice
     float* slice = queue + wave * (64 * E);
     int idx = 0;
 #pragma unroll
@@ -532,6 +526,11 @@ __device__ __forceinline__ void mm_iterate_block(float (&beta)[E], const RowY<E>
         const unsigned long long m = __ballot(big);
         if (big) slice[idx + __popcll(m & lt_mask)] = x1;
         idx += __popcll(m);
+    }
+    const bool wave_ok = __all(in_domain);
+    if (lane64 == 0) {
+        ctl->count[turn & 1][wave] = idx;
+        if (!wave_ok) ctl->bad = 1;
     }
     __syncthreads();
     const int c0 = ctl->count[turn & 1][0], c1 = ctl->count[turn & 1][1], c2 = ctl->count[turn & 1][2];
@@ -1020,6 +1019,13 @@ __global__ void k_selftest(unsigned long long* out) {
         b4 += differ1;
         if (differ0) { out[14] = f32_bits(a); out[15] = f32_bits(y); out[16] = f32_bits(ps); out[17] = f32_bits(up.x); out[18] = f32_bits(ug); }
         if (differ1) { out[14] = f32_bits(a2); out[15] = f32_bits(y); out[16] = f32_bits(ps); out[17] = f32_bits(up.y); out[18] = f32_bits(ug2); }
+    }
+    // (3, continued) the fp64 form of lgamma on every float of [1, 2.3): where it is sure it must agree
+    for (uint32_t b = f32_bits(1.0f) + tid; b < f32_bits(2.3f); b += nth) {
+        const float x = bits_f32(b);
+        bool sure;
+        const float fast = lgamma_sleef_1_23_f64(x, sure);
+        b3 += sure && f32_bits(fast) != f32_bits(lgamma_sleef_05_23(x));
     }
     atomicAdd(&out[0], b0); atomicAdd(&out[1], b1); atomicAdd(&out[2], b2);
     atomicAdd(&out[3], b3); atomicAdd(&out[4], b4); atomicAdd(&out[5], b5);

@@ -316,6 +316,40 @@ TCLIP_HD float lgamma_sleef_05_23(float x) {
     return z.x + z.y;
 }
 
+// The same function on [1, 2.3) (arguments alpha + 1 of the MM update) for a third of the cost.
+// There x - 1 and x - 2 are exact in fp32, so t carries no low word, and after the fp32 Horner
+// part the routine is three double-float multiply-adds and a product that hold ~46 good bits.
+// fp64 FMAs evaluate the same real expression to ~52 bits, so rounding that to fp32 gives the
+// double-float result's rounding unless the value sits within ~2^-40 (relative) of the midpoint
+// of two neighbouring floats.  `sure` says it does not (window: 2^15 of the 2^29 sub-float
+// positions); callers take lgamma_sleef_05_23 for the rest.  tests/test_math_host.py and
+// k_selftest compare the two on EVERY float of [1, 2.3): no unsure-free disagreement exists.
+TCLIP_HD float lgamma_tail_f64(float u, float t, bool o0, bool& sure) {   // u = the fp32 Horner part
+    const double td = (double)t;
+    double z = __builtin_fma((double)u, td, (double)(o0 ? -0.400686534596170958447352690395e+0f : -0.673523028297382446749257758235e-1f));
+    z = __builtin_fma(z, td, (double)(o0 ? +0.822466960142643054450325495997e+0f : +0.322467033928981157743538726901e+0f));
+    z = __builtin_fma(z, td, (double)(o0 ? -0.577215665946766039837398973297e+0f : +0.422784335087484338986941629852e+0f));
+    z = z * td + 0.0;                                             // + 0.0: t == 0 gives +0 as the double-float form does
+    const uint32_t below = (uint32_t)f64_bits(z) & 0x1fffffffu;   // the 29 mantissa bits an fp32 does not keep
+    sure = (below - (0x10000000u - 0x4000u)) > 0x8000u;           // not within 2^14 of the midpoint
+    return (float)z;
+}
+
+TCLIP_HD float lgamma_sleef_1_23_f64(float x, bool& sure) {
+    const bool o0 = x <= 1.2f;
+    const float t = x - (o0 ? 1.0f : 2.0f);
+    float u = o0 ? +0.9435157776e+0f : +0.1102489550e-3f;
+    u = __builtin_fmaf(u, t, o0 ? +0.8670063615e+0f : +0.8160019934e-4f);
+    u = __builtin_fmaf(u, t, o0 ? +0.4826702476e+0f : +0.1528468856e-3f);
+    u = __builtin_fmaf(u, t, o0 ? -0.8855129778e-1f : -0.2355068718e-3f);
+    u = __builtin_fmaf(u, t, o0 ? +0.1013825238e+0f : +0.4962242092e-3f);
+    u = __builtin_fmaf(u, t, o0 ? -0.1493408978e+0f : -0.1193488017e-2f);
+    u = __builtin_fmaf(u, t, o0 ? +0.1697509140e+0f : +0.2891599433e-2f);
+    u = __builtin_fmaf(u, t, o0 ? -0.2072454542e+0f : -0.7385451812e-2f);
+    u = __builtin_fmaf(u, t, o0 ? +0.2705872357e+0f : +0.2058077045e-1f);
+    return lgamma_tail_f64(u, t, o0, sure);
+}
+
 // x >= 2.3: Stirling series in 1/x on a double-float log; arguments up to 7 are first shifted
 // by 3, Gamma(x) = Gamma(x+3) / (x(x+1)(x+2)).
 template <bool kFast>

@@ -100,6 +100,29 @@ __device__ __forceinline__ f2 pk_lgamma_sleef_05_23(f2 x) {
     return z.x + z.y;
 }
 
+// lgamma on [1, 2.3) with the fp64 tail, see lgamma_sleef_1_23_f64; arguments it is not sure about
+// (6e-5 of them) send the wave through the double-float form.
+__device__ __forceinline__ f2 pk_lgamma_sleef_1_23(f2 x) {
+    const i2 o0 = x <= pk(1.2f);
+    const f2 t = x - pk_sel(o0, 1.0f, 2.0f);
+    f2 u = pk_sel(o0, +0.9435157776e+0f, +0.1102489550e-3f);
+    u = pk_fma(u, t, pk_sel(o0, +0.8670063615e+0f, +0.8160019934e-4f));
+    u = pk_fma(u, t, pk_sel(o0, +0.4826702476e+0f, +0.1528468856e-3f));
+    u = pk_fma(u, t, pk_sel(o0, -0.8855129778e-1f, -0.2355068718e-3f));
+    u = pk_fma(u, t, pk_sel(o0, +0.1013825238e+0f, +0.4962242092e-3f));
+    u = pk_fma(u, t, pk_sel(o0, -0.1493408978e+0f, -0.1193488017e-2f));
+    u = pk_fma(u, t, pk_sel(o0, +0.1697509140e+0f, +0.2891599433e-2f));
+    u = pk_fma(u, t, pk_sel(o0, -0.2072454542e+0f, -0.7385451812e-2f));
+    u = pk_fma(u, t, pk_sel(o0, +0.2705872357e+0f, +0.2058077045e-1f));
+    bool s0, s1;
+    f2 r{lgamma_tail_f64(u.x, t.x, o0.x != 0, s0), lgamma_tail_f64(u.y, t.y, o0.y != 0, s1)};
+    if (__builtin_expect(__ballot(!(s0 && s1)) != 0ull, 0)) {
+        const f2 slow = pk_lgamma_sleef_05_23(x);
+        r = f2{s0 ? r.x : slow.x, s1 ? r.y : slow.y};
+    }
+    return r;
+}
+
 // torch.sqrt, see sqrt_torch_inrange_f32
 __device__ __forceinline__ f2 pk_sqrt_torch_inrange(f2 x) {
     const f2 y{rsqrt14_f32(x.x), rsqrt14_f32(x.y)};
@@ -124,7 +147,7 @@ __device__ __forceinline__ f2 pk_mm_update_algebra(f2 a, f2 y, f2 psi_s, f2 psi1
 __device__ __forceinline__ f2 pk_mm_update(f2 a, f2 y, f2 psi_s, f2 lg_big, const LogTabEntry* tab) {
     const f2 x1 = a + pk(1.0f);
     const i2 big = x1 >= pk(2.3f);
-    const f2 lg_small = pk_lgamma_sleef_05_23(pk_sel(big, pk(2.0f), x1));
+    const f2 lg_small = pk_lgamma_sleef_1_23(pk_sel(big, pk(2.0f), x1));
     const f2 psi1 = pk_digamma_xp1(a, tab);
     return pk_mm_update_algebra(a, y, psi_s, psi1, pk_sel(big, lg_big, lg_small));
 }
