@@ -117,10 +117,10 @@ int tclip_probability_features(const float* visual, const float* text, int64_t n
                                float temperature, float* out, void* stream);
 
 /* Optional instrumentation used by bench.py (thread-local, off by default).  While enabled,
- * every launch of the majorize-minimize kernel issued by tclip_em_dirichlet_run on this thread is
- * bracketed by HIP events on the stream it is launched on (independent batches run on a few
- * internal streams, so launches overlap) and the element-updates it executes are counted on the
- * device.  tclip_profile_collect synchronises the device and returns, since the last collection:
+ * every launch of the live-row majorize-minimize kernel (k_mm_live, the dominant kernel) issued by
+ * tclip_em_dirichlet_run on this thread is bracketed by HIP events on the stream it is launched
+ * on (independent batches run on a few internal streams, so launches overlap) and the
+ * element-updates it executes are counted on the device.  tclip_profile_collect synchronises the device and returns, since the last collection:
  * the time during which at least one such launch was running (union of the intervals), the sum
  * of the individual launch durations, the number of launches and the element-update count. */
 int tclip_profile_enable(int on);

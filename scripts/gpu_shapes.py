@@ -1,0 +1,27 @@
+"""Wall time of the engine on the other BASELINE shapes (run on the GPU box): python3 scripts/gpu_shapes.py"""
+import os, sys, time
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "transductive-clip_amd"))
+import torch
+from tclip_amd import engine, synth
+
+
+def timed(label, fn):
+    fn(); torch.cuda.synchronize()
+    t = time.time(); res = fn(); torch.cuda.synchronize(); dt = time.time() - t
+    print(f"{label}: {dt:.3f} s  mm_iters[0]={res.mm_iters[0].tolist()[:6]}...", flush=True)
+
+
+x, _ = synth.make_query_tasks(250, 1000, seed=5); x = x.cuda()
+timed("K=1000 zero-shot soft, 2 batches x 125 tasks, 20x1000",
+      lambda: engine.run_em_dirichlet(x, n_batches=2, iters=20, iter_mm=1000, lambd=200 * 75, hard=False))
+x, _ = synth.make_query_tasks(200, 397, seed=5); x = x.cuda()
+timed("K=397 zero-shot hard, 2 batches x 100 tasks, 10x1000",
+      lambda: engine.run_em_dirichlet(x, n_batches=2, iters=10, iter_mm=1000, lambd=79 * 75, hard=True))
+x, _ = synth.make_query_tasks(100, 100, seed=5, k_eff=5); xs, ys = synth.make_support(100, 100, 4, seed=5)
+x, xs, ys = x.cuda(), xs.cuda(), ys.squeeze(2).cuda()
+timed("K=100 few-shot 4-shot soft, 1 batch x 100 tasks, 20x1000",
+      lambda: engine.run_em_dirichlet(x, xs, ys, n_batches=1, iters=20, iter_mm=1000, lambd=20 * 75, hard=False))
+x, _ = synth.make_query_tasks(100, 10, seed=5); x = x.cuda()
+timed("K=10 zero-shot soft, 10 batches x 10 tasks, 20x1000",
+      lambda: engine.run_em_dirichlet(x, n_batches=10, iters=20, iter_mm=1000, lambd=2 * 75, hard=False))

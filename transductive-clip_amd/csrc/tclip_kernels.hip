@@ -1053,8 +1053,8 @@ static int fail(int code, const char* fmt, const char* detail = "") {
 
 static size_t align_up(size_t x) { return (x + 255) & ~(size_t)255; }
 
-// Optional instrumentation (bench.py): HIP events around every k_mm_chunk launch and a device
-// counter of executed element-updates.  Thread-local, off by default, never touched otherwise.
+// Optional instrumentation (bench.py): HIP events around every k_mm_live launch and a device
+// counter of the element-updates it executes.  Thread-local, off by default, never touched otherwise.
 struct Profile {
     bool on = false;
     std::vector<hipEvent_t> ev;      // start/stop pairs, reused across collections
@@ -1266,11 +1266,11 @@ static int enqueue_batches(const tclip_problem& p, const float* x_q, const float
             if (e0 && e1) TCLIP_HIP(hipEventRecord(e0, st));
             a.rows = live_rows; a.n_rows = counts + 1;
             dispatch_E<LaunchMMLive>(K, grid, st, a);
+            if (e0 && e1) TCLIP_HIP(hipEventRecord(e1, st));    // the instrumentation covers k_mm_live only
             if (zs && a.has_check) {          // dead rows only matter through their stop-test terms
-                a.rows = mm_rows; a.n_rows = counts;
+                a.rows = mm_rows; a.n_rows = counts; a.work_counter = nullptr;
                 dispatch_E<LaunchMM>(K, grid, st, a);
             }
-            if (e0 && e1) TCLIP_HIP(hipEventRecord(e1, st));
             hipLaunchKernelGGL(k_mm_decide, dim3(B), dim3(1024), 0, st, (const double*)rowpart, (const double*)cache,
                                (const uint8_t*)live, N * K, a.n_checks, c, a.has_check, a.l1, c == n_chunks - 1 ? 1 : 0,
                                p.iter_mm, stop, mm_iters + it, p.iters);
