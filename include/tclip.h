@@ -107,6 +107,17 @@ size_t tclip_soft_kmeans_workspace_bytes(const tclip_problem* p);
 int tclip_soft_kmeans_run(const tclip_problem* p, const float* x_q, float temperature, float* u, float* w,
                           int32_t* preds, void* workspace, size_t workspace_bytes, void* stream);
 
+/* HARD_KMEANS on probability features (reference: src/methods/zero_shot/hard_kmeans.py:26-35,
+ * 128-152, 186-204): centroids = means of the members, zero for empty clusters;
+ * u = one_hot(argmin_k softmax_k ||w_k - z_q||^2) (first minimum).  Same problem fields as
+ * SOFT_KMEANS (iters from p->iters, n_support = 0).
+ *   x_q device [T,Q,K] f32;  u device [T,Q,K] out (one-hot);  w device [T,K,K] out;
+ *   preds device [T,Q] i32 out;  criterions device [n_batches, iters] out: mean over the batch's
+ *   tasks of ||u_old - u||_F (the reference logs each value twice). */
+size_t tclip_hard_kmeans_workspace_bytes(const tclip_problem* p);
+int tclip_hard_kmeans_run(const tclip_problem* p, const float* x_q, float* u, float* w, int32_t* preds,
+                          float* criterions, void* workspace, size_t workspace_bytes, void* stream);
+
 /* Probability features from visual embeddings (reference: extract_features_softmax,
  * src/utils.py:287-290): out[n,:] = softmax_k(T * (visual[n]/||visual[n]||) . text[k]).
  *   visual device [n_rows, dim] f32 (any norm), text device [n_class, dim] f32 (unit-norm rows, as

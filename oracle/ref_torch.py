@@ -188,3 +188,32 @@ def run_soft_kmeans(x_q, *, n_class, iters, temperature):
         u = (temperature * logits).softmax(2)
         criterions.append((u.clone() - u).norm(dim=(1, 2)).mean(0))
     return {"u": u, "w": w, "criterions": torch.stack(criterions), "seconds": time.time() - t0}
+
+
+def run_hard_kmeans(x_q, *, n_class, iters):
+    """HARD_KMEANS on probability features, the reference's torch op sequence
+    (src/methods/zero_shot/hard_kmeans.py:26-35, 128-152, 186-204): w = u^T z / sum u with empty
+    clusters set to ZERO, u = one_hot(argmin_k softmax_k(||w_k - z_q||^2)) - the softmax is kept
+    because ties after its rounding decide the argmin.  Returns dict(u, w, criterions (iters,),
+    labels (iters,N,Q), seconds); the reference logs every criterion twice."""
+    query = x_q.clone().float()
+    t0 = time.time()
+    u = query.clone()
+    u_old = u.clone()
+    criterions, labels_all = [], []
+    w = None
+    for _ in range(iters):
+        num = (query.unsqueeze(2) * u.unsqueeze(3)).sum(1)
+        den = u.sum(1).clamp(min=EPS)
+        live = u.sum(1).unsqueeze(-1) > EPS
+        w = num.div_(den.unsqueeze(2)) * live
+        diff = w.unsqueeze(1) - query.unsqueeze(2)
+        logits = (diff.square_()).sum(dim=-1)
+        labels = torch.argmin(logits.softmax(2), dim=-1)
+        u = torch.zeros_like(u)
+        u.scatter_(2, labels.unsqueeze(-1), 1.0)
+        labels_all.append(labels.clone())
+        criterions.append((u_old - u).norm(dim=(1, 2)).mean(0))
+        u_old = u.clone()
+    return {"u": u, "w": w, "criterions": torch.stack(criterions), "labels": torch.stack(labels_all),
+            "seconds": time.time() - t0}

@@ -52,8 +52,9 @@ def load_reference_classes():
     from src.methods.few_shot.em_dirichlet import EM_DIRICHLET as FS
     from src.methods.few_shot.hard_em_dirichlet import HARD_EM_DIRICHLET as FSH
     from src.methods.zero_shot.soft_kmeans import SOFT_KMEANS as SKM
+    from src.methods.zero_shot.hard_kmeans import HARD_KMEANS as HKM
     sys.path.pop(0)
-    return {"zs_soft": ZS, "zs_hard": ZSH, "fs_soft": FS, "fs_hard": FSH, "zs_skm": SKM}
+    return {"zs_soft": ZS, "zs_hard": ZSH, "fs_soft": FS, "fs_hard": FSH, "zs_skm": SKM, "zs_hkm": HKM}
 
 
 # name: (kind, K, N, iters, shots, seed, full_alpha)
@@ -72,6 +73,10 @@ SMALL = {
     "zs_skm_K37_N6": ("zs_skm", 37, 6, 20, 0, 2021, True),
     "zs_skm_K100_N4": ("zs_skm", 100, 4, 20, 0, 2022, True),
     "zs_skm_K397_N2": ("zs_skm", 397, 2, 20, 0, 2023, True),
+    "zs_hkm_K10_N4": ("zs_hkm", 10, 4, 20, 0, 2020, True),
+    "zs_hkm_K37_N6": ("zs_hkm", 37, 6, 20, 0, 2021, True),
+    "zs_hkm_K100_N4": ("zs_hkm", 100, 4, 20, 0, 2022, True),
+    "zs_hkm_K397_N2": ("zs_hkm", 397, 2, 20, 0, 2023, True),
 }
 LARGE = {
     "zs_hard_K397_N2": ("zs_hard", 397, 2, 10, 0, 2023, False),
@@ -112,7 +117,7 @@ def run_case(name, spec, classes):
             norm_vals.append(float(r))
         return r
 
-    is_skm = kind == "zs_skm"
+    is_skm = kind in ("zs_skm", "zs_hkm")      # k-means family: no MM loop, the centroids stand in for alpha
     real_update_alpha = None if is_skm else m.update_alpha
 
     def traced_update_alpha(alpha_0, y_cst):
@@ -130,7 +135,8 @@ def run_case(name, spec, classes):
 
     def traced_u_update(q):
         real_u_update(q)
-        trace["argmax"].append(m.u.argmax(2).to(torch.int16).numpy().copy())
+        pick = m.u.argmin(2) if kind == "zs_hkm" else m.u.argmax(2)     # HARD_KMEANS assigns by argmin (hard_kmeans.py:193)
+        trace["argmax"].append(pick.to(torch.int16).numpy().copy())
 
     if not is_skm:
         m.update_alpha = traced_update_alpha

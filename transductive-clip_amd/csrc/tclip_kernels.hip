@@ -732,12 +732,13 @@ __global__ __launch_bounds__(256) void k_logits(const float* __restrict__ alpha,
     }
 }
 
-// SOFT_KMEANS E-step (soft_kmeans.py:105-125): logit[t,q,k] = T * (-1/2 * sum_d (w[t,k,d] - z[t,q,d])^2),
-// the sum in torch's last-dim order.  Same structure as k_logits.
+// k-means E-step: logit[t,q,k] = temperature * (pre * sum_d (w[t,k,d] - z[t,q,d])^2), the sum in torch's
+// last-dim order; SOFT_KMEANS (soft_kmeans.py:105-125): pre = -1/2, temperature = T; HARD_KMEANS
+// (hard_kmeans.py:26-35): pre = temperature = 1, i.e. the plain squared distance.  Same structure as k_logits.
 template <int E>
 __global__ __launch_bounds__(256) void k_kmeans_logits(const float* __restrict__ w, const float* __restrict__ z,
                                                        const int32_t* __restrict__ rows, const int32_t* __restrict__ n_rows,
-                                                       int Q, int K, float temperature, float* __restrict__ logit0) {
+                                                       int Q, int K, float pre, float temperature, float* __restrict__ logit0) {
     const int lane = threadIdx.x & (kGroup - 1);
     const int group = threadIdx.x / kGroup, groups_per_block = blockDim.x / kGroup;
     const int n = *n_rows;
@@ -760,16 +761,18 @@ __global__ __launch_bounds__(256) void k_kmeans_logits(const float* __restrict__
                 pr[e] = df * df;
             }
             const float ssum = group_sum_torch<E>(pr, K, lane);
-            if (lane == 0) logit0[((size_t)t * Q + q) * K + k] = temperature * (-0.5f * ssum);
+            if (lane == 0) logit0[((size_t)t * Q + q) * K + k] = temperature * (pre * ssum);
         }
     }
 }
 
 // E-step, part 3: u = softmax_k(logit0 + (lambd * v) / Q), torch CPU softmax order
 // (max, Sleef expf of the shifted row, 16-lane strided sum + butterfly, one reciprocal).
-// One 16-lane group per (task, query) row.  Also argmax (first maximum) and the hard one-hot.
-__global__ __launch_bounds__(256) void k_softmax(const float* __restrict__ logit0, const float* __restrict__ v, int TQ,
-                                                 int Q, int K, float lambd, int hard, float* __restrict__ u,
+// One 16-lane group per (task, query) row.  Also argmax (first maximum; pick_min: first minimum,
+// hard_kmeans.py:193) and the hard one-hot.  u may be logit0 itself (each entry is read before it
+// is written, by the same thread).
+__global__ __launch_bounds__(256) void k_softmax(const float* logit0, const float* __restrict__ v, int TQ,
+                                                 int Q, int K, float lambd, int hard, int pick_min, float* u,
                                                  int32_t* __restrict__ preds) {
     const int lane = threadIdx.x & 15;
     const int r = (blockIdx.x * blockDim.x + threadIdx.x) >> 4;
@@ -808,12 +811,13 @@ __global__ __launch_bounds__(256) void k_softmax(const float* __restrict__ logit
         total = acc;
     }
     const float inv = 1.0f / total;
-    float best = -1.0f;
+    const float sgn = pick_min ? -1.0f : 1.0f;       // compare sgn * u: softmax values lie in [0, 1]
+    float best = -2.0f;
     int best_k = 0x7fffffff;
     for (int k = lane; k < K; k += 16) {
         const float uv = ur[k] * inv;
         ur[k] = uv;
-        if (uv > best) { best = uv; best_k = k; }
+        if (sgn * uv > best) { best = sgn * uv; best_k = k; }
     }
 #pragma unroll
     for (int m = 8; m >= 1; m >>= 1) {
@@ -861,6 +865,35 @@ __global__ void k_criterion_mean(const float* __restrict__ ratio, int N, int for
     const float* r = ratio + (size_t)b * N;
     const float s = dsum_inner_serial(N, [&](int i) { return r[i]; });
     out[(size_t)b * stride] = force_zero ? 0.0f : s / (float)N;
+}
+
+// HARD_KMEANS helpers.  Centroids of empty clusters are zero (hard_kmeans.py:149-152).
+__global__ void k_zero_dead_rows(const uint8_t* __restrict__ live, int TK, int K, float* __restrict__ w) {
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < (size_t)TK * K; i += (size_t)gridDim.x * blockDim.x)
+        if (!live[i / K]) w[i] = 0.0f;
+}
+
+// Per task ||u_old - one_hot(labels)||_F (hard_kmeans.py:197), then u <- one_hot(labels).
+// One block per task, fp64 accumulation.
+__global__ __launch_bounds__(256) void k_hard_assign(const int32_t* __restrict__ labels, int Q, int K, float* __restrict__ u,
+                                                     float* __restrict__ change) {
+    const int t = blockIdx.x;
+    const size_t n = (size_t)Q * K, base = (size_t)t * n;
+    double a = 0.0;
+    for (size_t i = threadIdx.x; i < n; i += blockDim.x) {
+        const float hot = ((int)(i % K) == labels[(size_t)t * Q + i / K]) ? 1.0f : 0.0f;
+        const double d = (double)u[base + i] - (double)hot;
+        a += d * d;
+        u[base + i] = hot;
+    }
+    __shared__ double sh[256];
+    sh[threadIdx.x] = a;
+    __syncthreads();
+    for (int s2 = 128; s2 > 0; s2 >>= 1) {
+        if ((int)threadIdx.x < s2) sh[threadIdx.x] += sh[threadIdx.x + s2];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) change[t] = (float)__builtin_sqrt(sh[0]);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -1161,8 +1194,8 @@ template <int E> struct LaunchLogits {
 
 template <int E> struct LaunchKmeansLogits {
     static void run(int grid, hipStream_t st, const float* w, const float* z, const int32_t* rows, const int32_t* n,
-                    int Q, int K, float temperature, float* logit0) {
-        hipLaunchKernelGGL(k_kmeans_logits<E>, dim3(grid), dim3(256), 0, st, w, z, rows, n, Q, K, temperature, logit0);
+                    int Q, int K, float pre, float temperature, float* logit0) {
+        hipLaunchKernelGGL(k_kmeans_logits<E>, dim3(grid), dim3(256), 0, st, w, z, rows, n, Q, K, pre, temperature, logit0);
     }
 };
 
@@ -1284,7 +1317,7 @@ static int enqueue_batches(const tclip_problem& p, const float* x_q, const float
                                      (const int32_t*)live_rows, (const int32_t*)(counts + 1), Q, K, logit0);
         }
         hipLaunchKernelGGL(k_softmax, dim3((T * Q * 16 + 255) / 256), dim3(256), 0, st, (const float*)logit0, (const float*)v,
-                           T * Q, Q, K, (float)p.lambd, p.hard, u, preds);
+                           T * Q, Q, K, (float)p.lambd, p.hard, 0, u, preds);
         // ---- convergence record
         hipLaunchKernelGGL(k_criterion, dim3(T), dim3(256), 0, st, (const float*)alpha, alpha_old, K, ratio);
         hipLaunchKernelGGL(k_criterion_mean, dim3(B), dim3(64), 0, st, (const float*)ratio, N, (!zs && p.hard) ? 1 : 0,
@@ -1451,9 +1484,62 @@ int tclip_soft_kmeans_run(const tclip_problem* pp, const float* x_q, float tempe
         hipLaunchKernelGGL(k_build_rows, dim3((TK + 255) / 256), dim3(256), 0, st, (const uint8_t*)(it == 0 ? ones : live),
                            (const int32_t*)nullptr, TK, 0, scratch_rows, rows, counts);
         dispatch_E<LaunchKmeansLogits>(K, TK > 16384 ? 16384 : TK, st, (const float*)w, x_q, (const int32_t*)rows,
-                                       (const int32_t*)(counts + 1), Q, K, temperature, logit0);
+                                       (const int32_t*)(counts + 1), Q, K, -0.5f, temperature, logit0);
         hipLaunchKernelGGL(k_softmax, dim3((T * Q * 16 + 255) / 256), dim3(256), 0, st, (const float*)logit0,
-                           (const float*)nullptr, T * Q, Q, K, 0.0f, 0, u, preds);
+                           (const float*)nullptr, T * Q, Q, K, 0.0f, 0, 0, u, preds);
+    }
+    TCLIP_HIP(hipGetLastError());
+    return TCLIP_OK;
+}
+
+size_t tclip_hard_kmeans_workspace_bytes(const tclip_problem* p) {
+    if (check_problem(p) != TCLIP_OK) return 0;
+    size_t a, b, c, d, e, f, g;
+    return kmeans_ws_parts(*p, &a, &b, &c, &d, &e, &f, &g) + align_up((size_t)p->n_batches * p->tasks_per_batch * 4);
+}
+
+int tclip_hard_kmeans_run(const tclip_problem* pp, const float* x_q, float* u, float* w, int32_t* preds,
+                          float* criterions, void* workspace, size_t workspace_bytes, void* stream) {
+    if (int rc = check_problem(pp)) return rc;
+    const tclip_problem p = *pp;
+    if (!x_q || !u || !w || !preds || !criterions || !workspace) return fail(TCLIP_ERR_ARG, "null pointer argument");
+    if (p.n_support != 0) return fail(TCLIP_ERR_ARG, "HARD_KMEANS is a zero-shot method: n_support must be 0");
+    size_t o_cs, o_live, o_ones, o_logit, o_rows, o_scratch, o_counts;
+    const size_t o_change = kmeans_ws_parts(p, &o_cs, &o_live, &o_ones, &o_logit, &o_rows, &o_scratch, &o_counts);
+    if (workspace_bytes < tclip_hard_kmeans_workspace_bytes(pp)) return fail(TCLIP_ERR_WORKSPACE, "workspace smaller than tclip_hard_kmeans_workspace_bytes()");
+    if (((uintptr_t)workspace & 255) != 0) return fail(TCLIP_ERR_WORKSPACE, "workspace must be 256-byte aligned");
+    hipStream_t st = (hipStream_t)stream;
+    char* ws = (char*)workspace;
+    const int Q = p.n_query, K = p.n_class, B = p.n_batches, N = p.tasks_per_batch, T = B * N, TK = T * K;
+    const size_t TQK = (size_t)T * Q * K;
+    float* cs = (float*)(ws + o_cs);
+    uint8_t* live = (uint8_t*)(ws + o_live);
+    uint8_t* ones = (uint8_t*)(ws + o_ones);
+    float* logit0 = (float*)(ws + o_logit);
+    int32_t* rows = (int32_t*)(ws + o_rows);
+    int32_t* scratch_rows = (int32_t*)(ws + o_scratch);
+    int32_t* counts = (int32_t*)(ws + o_counts);
+    float* change = (float*)(ws + o_change);
+    hipLaunchKernelGGL(k_copy, dim3(ew_grid(TQK)), dim3(256), 0, st, x_q, u, TQK);          // u = z
+    TCLIP_HIP(hipMemsetAsync(ones, 1, (size_t)TK, st));
+    TCLIP_HIP(hipMemsetAsync(counts, 0, 256, st));
+    hipLaunchKernelGGL(k_build_rows, dim3((TK + 255) / 256), dim3(256), 0, st, (const uint8_t*)ones, (const int32_t*)nullptr,
+                       TK, 0, scratch_rows, rows, counts);                                  // every centroid, every iteration
+    for (int it = 0; it < p.iters; it++) {
+        // w_update: mean of the members, zero for empty clusters                            (hard_kmeans.py:138-152)
+        hipLaunchKernelGGL(k_cluster_sizes, dim3((TK + 255) / 256), dim3(256), 0, st, (const float*)u, T, Q, K, 1, cs,
+                           live, (float*)nullptr, (int32_t*)nullptr);
+        hipLaunchKernelGGL(k_mstats, dim3((K + 63) / 64, K, T), dim3(64), 0, st, (const float*)u, x_q, (const float*)cs,
+                           (const uint8_t*)live, (const float*)nullptr, (const float*)nullptr, Q, K, w);
+        hipLaunchKernelGGL(k_zero_dead_rows, dim3(ew_grid((size_t)TK * K)), dim3(256), 0, st, (const uint8_t*)live, TK, K, w);
+        // u_update + hard assignment: softmax of the squared distances, first minimum    (:128-136, :193-195)
+        dispatch_E<LaunchKmeansLogits>(K, TK > 16384 ? 16384 : TK, st, (const float*)w, x_q, (const int32_t*)rows,
+                                       (const int32_t*)(counts + 1), Q, K, 1.0f, 1.0f, logit0);
+        hipLaunchKernelGGL(k_softmax, dim3((T * Q * 16 + 255) / 256), dim3(256), 0, st, (const float*)logit0,
+                           (const float*)nullptr, T * Q, Q, K, 0.0f, 0, 1, logit0, preds);
+        // criterion mean_n ||u_old - u||_F, u <- one-hot                                       (:197-199)
+        hipLaunchKernelGGL(k_hard_assign, dim3(T), dim3(256), 0, st, (const int32_t*)preds, Q, K, u, change);
+        hipLaunchKernelGGL(k_criterion_mean, dim3(B), dim3(64), 0, st, (const float*)change, N, 0, criterions + it, p.iters);
     }
     TCLIP_HIP(hipGetLastError());
     return TCLIP_OK;

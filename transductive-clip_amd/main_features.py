@@ -9,7 +9,7 @@ src/utils.py:266-267) can run the task loop from them:
         --opts method em_dirichlet dataset caltech101 number_tasks 1000 batch_size 100 shots 0
 
 `--opts k v ...` follows main.py:24-33 (values are literal-eval'ed); defaults are those of
-config/main_config.yaml and config/methods_config/{em_dirichlet,hard_em_dirichlet,soft_kmeans}.yaml.
+config/main_config.yaml and config/methods_config/{em_dirichlet,hard_em_dirichlet,soft_kmeans,hard_kmeans}.yaml.
 Under `python -m torch.distributed.run --nproc-per-node N` batches are sharded over N GPUs.
 """
 import argparse
@@ -35,6 +35,7 @@ METHOD_DEFAULTS = {
     "em_dirichlet": dict(name_method="EM_DIRICHLET", iter=20, iter_mm=1000, graph_matching=True, tunable=False),
     "hard_em_dirichlet": dict(name_method="HARD_EM_DIRICHLET", iter=10, iter_mm=1000, graph_matching=True, tunable=False),
     "soft_kmeans": dict(name_method="SOFT_KMEANS", iter=20, graph_matching=True, tunable=False),
+    "hard_kmeans": dict(name_method="HARD_KMEANS", iter=10, graph_matching=True, tunable=False),
 }
 
 

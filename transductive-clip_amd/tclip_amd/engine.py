@@ -96,6 +96,34 @@ def run_soft_kmeans(x_q, *, iters, temperature):
     return u, w, preds
 
 
+def run_hard_kmeans(x_q, *, iters, n_batches=1):
+    """HARD_KMEANS: x_q (T,Q,K) f32 cuda -> (u one-hot (T,Q,K), w (T,K,K), preds (T,Q) i32,
+    criterions (n_batches, iters)), cuda, not synchronised."""
+    _require_cuda(x_q, "x_q")
+    x_q = x_q.contiguous().float()
+    T, Q, K = x_q.shape
+    if T % n_batches:
+        raise ValueError("the number of tasks must be a multiple of n_batches")
+    dev = x_q.device
+    p = _capi.Problem(n_batches, T // n_batches, Q, K, 0, iters, 1, 0, 0)
+    lib = _capi.lib()
+    ws_bytes = lib.tclip_hard_kmeans_workspace_bytes(ctypes.byref(p))
+    if ws_bytes == 0:
+        raise RuntimeError("tclip_hard_kmeans_workspace_bytes rejected the problem: " + lib.tclip_last_error().decode())
+    with torch.cuda.device(dev):
+        ws = torch.empty(ws_bytes + 256, dtype=torch.uint8, device=dev)
+        off = (-ws.data_ptr()) % 256
+        u = torch.empty(T, Q, K, device=dev)
+        w = torch.empty(T, K, K, device=dev)
+        preds = torch.empty(T, Q, dtype=torch.int32, device=dev)
+        crit = torch.empty(n_batches, iters, device=dev)
+        rc = lib.tclip_hard_kmeans_run(ctypes.byref(p), _ptr(x_q), _ptr(u), _ptr(w), _ptr(preds), _ptr(crit),
+                                       ctypes.c_void_p(ws.data_ptr() + off), ws_bytes, _stream())
+        _capi.check(rc, "tclip_hard_kmeans_run")
+        ws.record_stream(torch.cuda.current_stream())
+    return u, w, preds, crit
+
+
 def clustering_accuracy(x_q, preds, y_q, graph_matching=True):
     """Zero-shot accuracy tail: device prototypes of the predicted clusters, host assignment.
 
