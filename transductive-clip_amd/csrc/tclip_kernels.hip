@@ -17,6 +17,7 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <stdio.h>
+#include <stdlib.h>
 #include <string.h>
 
 #include <algorithm>
@@ -1327,10 +1328,11 @@ static int enqueue_batches(const tclip_problem& p, const float* x_q, const float
     return TCLIP_OK;
 }
 
-// Independent batches are spread over a few internal HIP streams (forked from and joined to the
-// caller's stream with events): every MM launch is a barrier for the batches it covers, and with
-// equal-length rows its last round of waves leaves SIMDs idle; kernels of another group fill them.
-constexpr int kMaxGroups = 4;
+// Independent batches are spread over up to three streams (the caller's and two internal ones,
+// forked from and joined to the caller's stream with events): every MM launch is a barrier for the
+// batches it covers, and with equal-length rows its last round of waves leaves SIMDs idle; kernels
+// of another group fill them.
+constexpr int kMaxGroups = 16;
 struct StreamPool {
     hipStream_t s[kMaxGroups] = {};
     hipEvent_t fork = nullptr, join[kMaxGroups] = {};
@@ -1358,7 +1360,26 @@ static int pool_init() {
     return TCLIP_OK;
 }
 
-static int n_groups_of(const tclip_problem& p) { return p.n_batches < kMaxGroups ? p.n_batches : kMaxGroups; }
+// Group 0 runs on the caller's stream, the others on pool streams.  Measured on the K=100 bench
+// (10 batches): 1 group 685 ms per step, 2 or 3 groups 606 ms, 4 groups 685 ms again with HIP's
+// default of four hardware queues per process (streams beyond the queues serialise behind each
+// other; GPU_MAX_HW_QUEUES=8 brings 4 groups to 619 ms).  Small problems are launch-bound and
+// run best on one stream (K=10, 10 batches of 10 tasks: 53 ms against 114 ms on four).
+static int stream_groups() {
+    static const int n = [] {
+        const char* e = getenv("TCLIP_STREAM_GROUPS");           // tuning knob, 1..16
+        const int v = e ? atoi(e) : 3;
+        return v < 1 ? 1 : (v > kMaxGroups ? kMaxGroups : v);
+    }();
+    return n;
+}
+static int n_groups_of(const tclip_problem& p) {
+    const long long rows = (long long)p.n_batches * p.tasks_per_batch * p.n_class;
+    long long g = rows / 8192;                                   // a group should fill the machine once
+    if (g > stream_groups()) g = stream_groups();
+    if (g > p.n_batches) g = p.n_batches;
+    return g < 1 ? 1 : (int)g;
+}
 
 static tclip_problem group_problem(const tclip_problem& p, int g, int* first_batch) {
     const int G = n_groups_of(p), base = p.n_batches / G, extra = p.n_batches % G;
@@ -1400,26 +1421,29 @@ int tclip_em_dirichlet_run(const tclip_problem* pp, const float* x_q, const floa
         if (int rc = pool_init()) return rc;
         TCLIP_HIP(hipEventRecord(g_pool.fork, caller));
     }
-    char* ws = (char*)workspace;
     const size_t N = p.tasks_per_batch, Q = p.n_query, K = p.n_class, S = p.n_support;
+    size_t ws_off[kMaxGroups + 1] = {0};
     for (int g = 0; g < G; g++) {
+        int b0;
+        ws_off[g + 1] = ws_off[g] + make_layout(group_problem(p, g, &b0)).total;
+    }
+    for (int i = 0; i < G; i++) {
+        const int g = (i + 1) % G;                       // pool streams first, the caller's stream last
         int b0;
         const tclip_problem q = group_problem(p, g, &b0);
         const size_t t0 = (size_t)b0 * N;
-        hipStream_t st = G > 1 ? g_pool.s[g] : caller;
-        if (G > 1) TCLIP_HIP(hipStreamWaitEvent(st, g_pool.fork, 0));
+        hipStream_t st = g == 0 ? caller : g_pool.s[g];
+        if (g != 0) TCLIP_HIP(hipStreamWaitEvent(st, g_pool.fork, 0));
         tclip_problem qs = q;
         qs.iters = p.iters;
         if (int rc = enqueue_batches(qs, x_q + t0 * Q * K, zs ? nullptr : x_s + t0 * S * K, zs ? nullptr : y_s + t0 * S,
                                      u + t0 * Q * K, v + t0 * K, alpha + t0 * K * K, preds + t0 * Q,
-                                     criterions + (size_t)b0 * p.iters, mm_iters + (size_t)b0 * p.iters, ws, st))
+                                     criterions + (size_t)b0 * p.iters, mm_iters + (size_t)b0 * p.iters,
+                                     (char*)workspace + ws_off[g], st))
             return rc;
-        ws += make_layout(q).total;
-        if (G > 1) {
-            TCLIP_HIP(hipEventRecord(g_pool.join[g], st));
-            TCLIP_HIP(hipStreamWaitEvent(caller, g_pool.join[g], 0));
-        }
+        if (g != 0) TCLIP_HIP(hipEventRecord(g_pool.join[g], st));
     }
+    for (int g = 1; g < G; g++) TCLIP_HIP(hipStreamWaitEvent(caller, g_pool.join[g], 0));
     return TCLIP_OK;
 }
 
