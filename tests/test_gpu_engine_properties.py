@@ -49,6 +49,31 @@ def test_engine_equals_cpu_oracle_on_fresh_inputs(K, N, B, hard, few):
             assert (res.criterions[b].cpu().numpy() == 0).all()
 
 
+@pytest.mark.parametrize("K,N", [(12, 3), (40, 4)])
+def test_nan_in_one_task_leaves_the_others_exact(K, N):
+    """A NaN feature poisons its own task (as in the reference) and pushes every block that holds
+    one of that task's rows onto the generic IEEE path of the MM kernel, iteration after iteration;
+    the other tasks of the batch must still come out bit-identical to the oracle's, which also
+    pins the generic path to the fast one on real trajectories.  The batch criterion is NaN, so no
+    early stop on either side."""
+    from oracle import c_oracle
+    from tclip_amd import engine, synth
+    iters, iter_mm, lambd = 3, 120, int(K / 5) * 75
+    x_q, _ = synth.make_query_tasks(N, K, seed=900 + K)
+    x_q[1, 5, 3] = float("nan")
+    res = engine.run_em_dirichlet(x_q.cuda(), n_batches=1, iters=iters, iter_mm=iter_mm, lambd=lambd, hard=False)
+    torch.cuda.synchronize()
+    ref = c_oracle.run(x_q.numpy(), iters=iters, iter_mm=iter_mm, lambd=lambd, hard=False)
+    assert np.array_equal(res.mm_iters[0].cpu().numpy(), ref["mm_iters"]) and (ref["mm_iters"] == iter_mm).all()
+    clean = [t for t in range(N) if t != 1]
+    assert np.array_equal(res.alpha[clean].cpu().numpy(), ref["alpha"][clean])
+    assert np.array_equal(res.u[clean].cpu().numpy(), ref["u"][clean])
+    assert np.array_equal(res.v[clean].cpu().numpy(), ref["v"][clean])
+    assert np.isfinite(ref["alpha"][clean]).all()
+    assert np.array_equal(np.isnan(res.alpha[1].cpu().numpy()), np.isnan(ref["alpha"][1]))
+    assert np.isnan(ref["alpha"][1]).any()
+
+
 @pytest.mark.parametrize("K,Q,iter_mm,hard", [(6, 75, 30, False), (9, 75, 51, False), (11, 40, 101, True), (3, 75, 120, False),
                                                (4, 75, 120, True), (32, 20, 150, False), (64, 75, 52, False)])
 def test_edge_shapes_and_schedules(K, Q, iter_mm, hard):
