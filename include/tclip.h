@@ -118,6 +118,19 @@ size_t tclip_hard_kmeans_workspace_bytes(const tclip_problem* p);
 int tclip_hard_kmeans_run(const tclip_problem* p, const float* x_q, float* u, float* w, int32_t* preds,
                           float* criterions, void* workspace, size_t workspace_bytes, void* stream);
 
+/* PADDLE on probability features (reference: src/methods/few_shot/paddle.py:94-219; feature
+ * dimension = n_class).  Prototypes start as the class means of the support set; each iteration:
+ * u = softmax_k(-1/2 ||w_k - z_q||^2 + lambd v_k / Q), v = log(mean_q u + eps) + 1,
+ * w = (sum_q u z + support sums) / (sum_q u + support counts).  Uses n_batches * tasks_per_batch
+ * tasks, n_query, n_class, n_support and iters; lambd is the method's float (paddle.yaml).
+ *   x_q device [T,Q,K] f32;  x_s device [T,S,K] f32;  y_s device [T,S] i64;
+ *   u device [T,Q,K] out;  v device [T,K] out;  w device [T,K,K] out;  preds device [T,Q] i32 out
+ *   (argmax of u).  The criterion the reference logs is identically 0. */
+size_t tclip_paddle_workspace_bytes(const tclip_problem* p);
+int tclip_paddle_run(const tclip_problem* p, const float* x_q, const float* x_s, const int64_t* y_s, float lambd,
+                     float* u, float* v, float* w, int32_t* preds, void* workspace, size_t workspace_bytes,
+                     void* stream);
+
 /* Probability features from visual embeddings (reference: extract_features_softmax,
  * src/utils.py:287-290): out[n,:] = softmax_k(T * (visual[n]/||visual[n]||) . text[k]).
  *   visual device [n_rows, dim] f32 (any norm), text device [n_class, dim] f32 (unit-norm rows, as

@@ -217,3 +217,34 @@ def run_hard_kmeans(x_q, *, n_class, iters):
         u_old = u.clone()
     return {"u": u, "w": w, "criterions": torch.stack(criterions), "labels": torch.stack(labels_all),
             "seconds": time.time() - t0}
+
+
+def run_paddle(x_q, x_s, y_s, *, n_class, iters, lambd):
+    """PADDLE on probability features, the reference's torch op sequence
+    (src/methods/few_shot/paddle.py:94-219): prototypes from the support class means, then
+    u = softmax_k(-1/2 ||w_k - z_q||^2 + lambd v_k / Q), v = log(mean_q u + eps) + 1,
+    w = (sum_q u z + support sums) / (sum_q u + support counts).  Returns dict(u, v, w, criterions,
+    argmax (iters,N,Q), seconds); the logged criterion is identically 0."""
+    query, support = x_q.clone().float(), x_s.clone().float()
+    n_task, n_query = query.shape[0], query.shape[1]
+    t0 = time.time()
+    v = torch.zeros(n_task, n_class)
+    ys_hot = one_hot_rows(y_s.long().view(n_task, -1), n_class)
+    counts = ys_hot.sum(1).unsqueeze(-1)
+    w = (ys_hot.unsqueeze(-1) * support.unsqueeze(2)).sum(1).div_(counts)
+    criterions, argmax = [], []
+    u = query.clone()
+    for _ in range(iters):
+        diff = w.unsqueeze(1) - query.unsqueeze(2)
+        logits = -1 / 2 * (diff.square_()).sum(dim=-1)
+        u = (logits + lambd * v.unsqueeze(1) / n_query).softmax(2)
+        argmax.append(u.argmax(2).clone())
+        v = torch.log(u.sum(1) / u.size(1) + EPS) + 1
+        num = (query.unsqueeze(2) * u.unsqueeze(3)).sum(1)
+        den = u.sum(1)
+        num.add_((support.unsqueeze(2) * ys_hot.unsqueeze(3)).sum(1))
+        den.add_(ys_hot.sum(1))
+        w = num.div_(den.unsqueeze(2))
+        criterions.append((u.clone() - u).norm(dim=(1, 2)).mean(0))
+    return {"u": u, "v": v, "w": w, "criterions": torch.stack(criterions), "argmax": torch.stack(argmax),
+            "seconds": time.time() - t0}

@@ -25,3 +25,7 @@ timed("K=100 few-shot 4-shot soft, 1 batch x 100 tasks, 20x1000",
 x, _ = synth.make_query_tasks(100, 10, seed=5); x = x.cuda()
 timed("K=10 zero-shot soft, 10 batches x 10 tasks, 20x1000",
       lambda: engine.run_em_dirichlet(x, n_batches=10, iters=20, iter_mm=1000, lambd=2 * 75, hard=False))
+x, _ = synth.make_query_tasks(8, 1000, seed=5, k_eff=5); xs, ys = synth.make_support(8, 1000, 4, seed=5)
+x, xs, ys = x.cuda(), xs.cuda(), ys.squeeze(2).cuda()
+timed("K=1000 few-shot 4-shot soft, 1 batch x 8 tasks, 20x1000 (configs[4] shape)",
+      lambda: engine.run_em_dirichlet(x, xs, ys, n_batches=1, iters=20, iter_mm=1000, lambd=200 * 75, hard=False))

@@ -40,9 +40,9 @@ class Args(dict):
     __setattr__ = dict.__setitem__
 
 
-def make_args(K, iters, iter_mm=1000, k_eff=5, shots=0):
+def make_args(K, iters, iter_mm=1000, k_eff=5, shots=0, lambd=0.0):
     return Args(iter=iters, iter_mm=iter_mm, num_classes_test=K, n_class=K, n_query=75,
-                k_eff=k_eff, T=30, use_softmax_feature=True, graph_matching=True, shots=shots)
+                k_eff=k_eff, T=30, use_softmax_feature=True, graph_matching=True, shots=shots, lambd=lambd)
 
 
 def load_reference_classes():
@@ -53,8 +53,16 @@ def load_reference_classes():
     from src.methods.few_shot.hard_em_dirichlet import HARD_EM_DIRICHLET as FSH
     from src.methods.zero_shot.soft_kmeans import SOFT_KMEANS as SKM
     from src.methods.zero_shot.hard_kmeans import HARD_KMEANS as HKM
+    from src.methods.few_shot.paddle import PADDLE
     sys.path.pop(0)
-    return {"zs_soft": ZS, "zs_hard": ZSH, "fs_soft": FS, "fs_hard": FSH, "zs_skm": SKM, "zs_hkm": HKM}
+    return {"zs_soft": ZS, "zs_hard": ZSH, "fs_soft": FS, "fs_hard": FSH, "zs_skm": SKM, "zs_hkm": HKM,
+            "fs_paddle": PADDLE}
+
+
+# PADDLE's lambd is a tunable float (paddle.yaml: 0.0); the fixtures also use a value that makes the
+# class-proportion term matter
+PADDLE_LAMBD = {"fs_paddle_K10_N4_s4": 0.0, "fs_paddle_K37_N3_s2": 20.0, "fs_paddle_K100_N3_s1": 5.0,
+                "fs_paddle_K397_N1_s1": 10.0}
 
 
 # name: (kind, K, N, iters, shots, seed, full_alpha)
@@ -77,6 +85,10 @@ SMALL = {
     "zs_hkm_K37_N6": ("zs_hkm", 37, 6, 20, 0, 2021, True),
     "zs_hkm_K100_N4": ("zs_hkm", 100, 4, 20, 0, 2022, True),
     "zs_hkm_K397_N2": ("zs_hkm", 397, 2, 20, 0, 2023, True),
+    "fs_paddle_K10_N4_s4": ("fs_paddle", 10, 4, 20, 4, 2020, True),
+    "fs_paddle_K37_N3_s2": ("fs_paddle", 37, 3, 20, 2, 2021, True),
+    "fs_paddle_K100_N3_s1": ("fs_paddle", 100, 3, 20, 1, 2022, True),
+    "fs_paddle_K397_N1_s1": ("fs_paddle", 397, 1, 20, 1, 2023, True),
 }
 LARGE = {
     "zs_hard_K397_N2": ("zs_hard", 397, 2, 10, 0, 2023, False),
@@ -94,7 +106,7 @@ def run_case(name, spec, classes):
     if few:
         x_s, y_s = synth.make_support(N, K, shots, seed=seed)
         task["x_s"], task["y_s"] = x_s.clone(), y_s.clone()
-    args = make_args(K, iters, shots=shots)
+    args = make_args(K, iters, shots=shots, lambd=PADDLE_LAMBD.get(name, 0.0))
     m = classes[kind](model=None, device=torch.device("cpu"), log_file=os.path.join("/tmp", "golden.log"),
                       args=args)
 
@@ -117,7 +129,7 @@ def run_case(name, spec, classes):
             norm_vals.append(float(r))
         return r
 
-    is_skm = kind in ("zs_skm", "zs_hkm")      # k-means family: no MM loop, the centroids stand in for alpha
+    is_skm = kind in ("zs_skm", "zs_hkm", "fs_paddle")      # k-means family: no MM loop, the centroids stand in for alpha
     real_update_alpha = None if is_skm else m.update_alpha
 
     def traced_update_alpha(alpha_0, y_cst):
@@ -161,7 +173,8 @@ def run_case(name, spec, classes):
         "stop_test": np.stack(trace["stop_test"]) if trace["stop_test"] else np.zeros(0),   # norms seen by the MM stop test
         "criterions": np.asarray(logs["criterions"], np.float32),
         "acc": np.asarray(logs["acc"], np.float32),
-        "v": np.zeros(0) if is_skm else m.v.numpy(),
+        "v": m.v.numpy() if hasattr(m, "v") and kind != "zs_skm" and kind != "zs_hkm" else np.zeros(0),
+        "lambd": float(args.lambd),
         "torch_version": torch.__version__, "ref_seconds": dt,
     }
     if few:

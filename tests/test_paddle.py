@@ -1,0 +1,76 @@
+"""PADDLE: the torch-eager oracle against the golden vectors produced by the
+reference (CPU), and the HIP path against the same vectors (GPU).  Everything is bit-exact:
+prototypes, responsibilities, v, per-iteration argmax, accuracies."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import GOLDEN, golden_names
+from oracle import ref_torch
+
+NAMES = golden_names("fs_paddle_")
+
+
+def test_fixtures_present():
+    assert len(NAMES) == 4
+
+
+@pytest.mark.parametrize("name", NAMES)
+def test_oracle_reproduces_reference(name):
+    g = np.load(os.path.join(GOLDEN, name + ".npz"))
+    if str(g["torch_version"]) != torch.__version__:
+        pytest.skip("fixtures were made with another torch build")
+    K = int(g["K"])
+    t = ref_torch.run_paddle(torch.from_numpy(g["x_q"]), torch.from_numpy(g["x_s"]), torch.from_numpy(g["y_s"]),
+                             n_class=K, iters=int(g["iters"]), lambd=float(g["lambd"]))
+    assert np.array_equal(t["w"].numpy(), g["alpha"]) and np.array_equal(t["u"].numpy(), g["u"])
+    assert np.array_equal(t["v"].numpy(), g["v"])
+    assert np.array_equal(t["argmax"].numpy().astype(np.int16), g["argmax"])
+    assert np.array_equal(t["criterions"].numpy(), g["criterions"]) and (g["criterions"] == 0).all()
+    acc = (t["u"].argmax(2) == torch.from_numpy(g["y_q"]).squeeze(2)).float().mean(1, keepdim=True)
+    assert np.array_equal(acc.numpy(), g["acc"])
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name", NAMES)
+def test_engine_matches_reference(name):
+    from src.methods.few_shot.paddle import PADDLE
+    from src.utils import CfgNode
+    g = np.load(os.path.join(GOLDEN, name + ".npz"))
+    K = int(g["K"])
+    a = CfgNode(iter=int(g["iters"]), num_classes_test=K, n_class=K, n_query=75, k_eff=5, T=30, shots=int(g["shots"]),
+                use_softmax_feature=True, lambd=float(g["lambd"]))
+    m = PADDLE(model=None, device=torch.device("cuda:0"), log_file=None, args=a)
+    logs = m.run_task(task_dic={"x_q": torch.from_numpy(g["x_q"]), "y_q": torch.from_numpy(g["y_q"]),
+                                "x_s": torch.from_numpy(g["x_s"]), "y_s": torch.from_numpy(g["y_s"])}, shot=int(g["shots"]))
+    assert np.array_equal(m.w.cpu().numpy(), g["alpha"]), "prototypes differ"
+    assert np.array_equal(m.u.cpu().numpy(), g["u"]), "responsibilities differ"
+    assert np.array_equal(m.v.cpu().numpy(), g["v"]), "v differs"
+    assert np.array_equal(m.preds.cpu().numpy(), g["argmax"][-1].astype(np.int32))
+    assert np.array_equal(logs["acc"], g["acc"])
+    assert np.array_equal(logs["criterions"], g["criterions"])
+
+
+@pytest.mark.gpu
+def test_engine_close_to_oracle_on_fresh_tasks():
+    """Seeded inputs no fixture holds.  The oracle here is torch on the GPU box's own host, whose
+    MKL may dispatch another vsLn kernel than the host the fixtures were made on (observed: 4 % of
+    the v entries one ulp apart), so this comparison carries a tolerance; bit-exactness is pinned
+    by the fixtures above."""
+    from tclip_amd import engine, synth
+    K, N, shots = 21, 5, 2
+    x_q, _ = synth.make_query_tasks(N, K, seed=31, k_eff=4)
+    x_s, y_s = synth.make_support(N, K, shots, seed=31)
+    u, v, w, preds = engine.run_paddle(x_q.cuda(), x_s.cuda(), y_s.squeeze(2).cuda(), iters=7, lambd=12.5)
+    torch.cuda.synchronize()
+    t = ref_torch.run_paddle(x_q, x_s, y_s, n_class=K, iters=7, lambd=12.5)
+    torch.testing.assert_close(u.cpu(), t["u"], rtol=1e-5, atol=1e-8)
+    torch.testing.assert_close(w.cpu(), t["w"], rtol=1e-5, atol=1e-8)
+    torch.testing.assert_close(v.cpu(), t["v"], rtol=1e-5, atol=1e-7)
+    # with lambd = 0 nothing of v feeds back, and one iteration has no log in it at all: exact
+    u0, _, w0, p0 = engine.run_paddle(x_q.cuda(), x_s.cuda(), y_s.squeeze(2).cuda(), iters=3, lambd=0.0)
+    t0 = ref_torch.run_paddle(x_q, x_s, y_s, n_class=K, iters=3, lambd=0.0)
+    assert torch.equal(u0.cpu(), t0["u"]) and torch.equal(w0.cpu(), t0["w"])
+    assert torch.equal(p0.cpu().long(), t0["argmax"][-1])

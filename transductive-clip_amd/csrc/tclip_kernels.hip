@@ -94,7 +94,7 @@ struct SparseCascade {
 // it).  Because a1 then holds exactly what the first dump put there, replaying "first level-1
 // boundary, then first level-2 boundary >= it, then first level-3 boundary >= that" is equivalent.
 
-__global__ void k_support_stats(const float* __restrict__ xs, const int64_t* __restrict__ ys, int S, int K,
+__global__ void k_support_stats(const float* __restrict__ xs, const int64_t* __restrict__ ys, int S, int K, int take_log,
                                 float* __restrict__ sup, float* __restrict__ cnt) {
     extern __shared__ int members[];               // indices s with ys == k, ascending
     __shared__ int n_members;
@@ -129,7 +129,10 @@ __global__ void k_support_stats(const float* __restrict__ xs, const int64_t* __r
         float r;
         if (col < (ncols / 32) * 32) {
             SparseCascade c(S);
-            for (int i = 0; i < nm; i++) c.add(members[i], log_f32(xt[(size_t)members[i] * K + d] + kEpsF));
+            for (int i = 0; i < nm; i++) {
+                const float x = xt[(size_t)members[i] * K + d];
+                c.add(members[i], take_log ? log_f32(x + kEpsF) : x);
+            }
             r = c.finish();
         } else {   // 4 interleaved cascades over s/4, leftovers (s >= 4*(S/4)) into partial 0
             const int size_ilp = S >> 2;
@@ -140,7 +143,8 @@ __global__ void k_support_stats(const float* __restrict__ xs, const int64_t* __r
             // leftovers are added after partial 0's cascade is complete, in order
             for (int i = 0; i < nm; i++) {
                 const int s = members[i];
-                const float v = log_f32(xt[(size_t)s * K + d] + kEpsF);
+                const float x = xt[(size_t)s * K + d];
+                const float v = take_log ? log_f32(x + kEpsF) : x;
                 if (s >= size_ilp * 4) {
                     if (!has_extra) { p0 = c0.finish(); has_extra = true; }
                     p0 += v;
@@ -186,11 +190,12 @@ __global__ void k_cluster_sizes(const float* __restrict__ u, int T, int Q, int K
 
 // y[t,k,d] = sum_q u[t,q,k] * f[t,q,d] / max(cs, eps)                         (zero-shot, live rows)
 //          = (sup[t,k,d] + sum_q u f) * (1 / (cnt[t,k] + cs[t,k]))           (few-shot)
+//          = (sum_q u f + sup[t,k,d]) / (cs[t,k] + cnt[t,k])                 (PADDLE centroids)
 // The same kernel, with f = raw features and u = one-hot predictions, gives the cluster
 // prototypes of the accuracy tail (em_dirichlet.py:66-67).
 __global__ void k_mstats(const float* __restrict__ u, const float* __restrict__ f, const float* __restrict__ cs,
                          const uint8_t* __restrict__ live, const float* __restrict__ sup,
-                         const float* __restrict__ cnt, int Q, int K, float* __restrict__ y) {
+                         const float* __restrict__ cnt, int Q, int K, float* __restrict__ y, int paddle = 0) {
     const int t = blockIdx.z, k = blockIdx.y;
     const int d = blockIdx.x * blockDim.x + threadIdx.x;
     const size_t row = (size_t)t * K + k;
@@ -200,7 +205,9 @@ __global__ void k_mstats(const float* __restrict__ u, const float* __restrict__ 
     float s = dsum_outer(Q, (long)k * K + d, (long)K * K,
                          [&](int q) { return ut[(size_t)q * K] * ft[(size_t)q * K]; });
     const float c = cs[row];
-    if (sup) {
+    if (sup && paddle) {           // PADDLE centroid (few_shot/paddle.py:154-158): (sum_q u z + support sum) / (sum_q u + count)
+        y[row * K + d] = (s + sup[row * K + d]) / (c + cnt[row]);
+    } else if (sup) {
         const float w = 1.0f / (cnt[row] + c);
         y[row * K + d] = w * (sup[row * K + d] + s);
     } else {
@@ -868,6 +875,12 @@ __global__ void k_criterion_mean(const float* __restrict__ ratio, int N, int for
     out[(size_t)b * stride] = force_zero ? 0.0f : s / (float)N;
 }
 
+// PADDLE prototype initialisation (few_shot/paddle.py:127-140): class means of the support set.
+__global__ void k_div_rows(const float* __restrict__ num, const float* __restrict__ den, size_t n, int K, float* __restrict__ out) {
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x)
+        out[i] = num[i] / den[i / K];
+}
+
 // HARD_KMEANS helpers.  Centroids of empty clusters are zero (hard_kmeans.py:149-152).
 __global__ void k_zero_dead_rows(const uint8_t* __restrict__ live, int TK, int K, float* __restrict__ w) {
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < (size_t)TK * K; i += (size_t)gridDim.x * blockDim.x)
@@ -1257,7 +1270,7 @@ static int enqueue_batches(const tclip_problem& p, const float* x_q, const float
     hipLaunchKernelGGL(k_fill, dim3(ew_grid(TK)), dim3(256), 0, st, v, 0.0f, (size_t)TK);
     TCLIP_HIP(hipMemsetAsync(cache_len, 0, (size_t)TK * 4, st));
     if (!zs) {
-        hipLaunchKernelGGL(k_support_stats, dim3(K, T), dim3(128), (size_t)S * sizeof(int), st, x_s, y_s, S, K, sup, cnt);
+        hipLaunchKernelGGL(k_support_stats, dim3(K, T), dim3(128), (size_t)S * sizeof(int), st, x_s, y_s, S, K, 1, sup, cnt);
     }
     // E-step terms of the initial alpha = 1 for every row (rows that never come alive keep them):
     // use the full-row list 0..TK-1 once.
@@ -1564,6 +1577,76 @@ int tclip_hard_kmeans_run(const tclip_problem* pp, const float* x_q, float* u, f
         // criterion mean_n ||u_old - u||_F, u <- one-hot                                       (:197-199)
         hipLaunchKernelGGL(k_hard_assign, dim3(T), dim3(256), 0, st, (const int32_t*)preds, Q, K, u, change);
         hipLaunchKernelGGL(k_criterion_mean, dim3(B), dim3(64), 0, st, (const float*)change, N, 0, criterions + it, p.iters);
+    }
+    TCLIP_HIP(hipGetLastError());
+    return TCLIP_OK;
+}
+
+// ---- PADDLE: few-shot soft k-means with the class-proportion penalty
+static size_t paddle_ws_parts(const tclip_problem& p, size_t* o_sup, size_t* o_cnt, size_t* o_cs, size_t* o_live,
+                              size_t* o_logit, size_t* o_rows, size_t* o_scratch_rows, size_t* o_counts) {
+    const size_t T = (size_t)p.n_batches * p.tasks_per_batch, K = p.n_class, Q = p.n_query;
+    size_t o = 0;
+    auto take = [&](size_t bytes) { size_t r = o; o += align_up(bytes); return r; };
+    *o_sup = take(T * K * K * 4);
+    *o_cnt = take(T * K * 4);
+    *o_cs = take(T * K * 4);
+    *o_live = take(T * K);
+    *o_logit = take(T * Q * K * 4);
+    *o_rows = take(T * K * 4);
+    *o_scratch_rows = take(T * K * 4);
+    *o_counts = take(256);
+    return o;
+}
+
+size_t tclip_paddle_workspace_bytes(const tclip_problem* p) {
+    if (check_problem(p) != TCLIP_OK) return 0;
+    size_t a, b, c, d, e, f, g, h;
+    return paddle_ws_parts(*p, &a, &b, &c, &d, &e, &f, &g, &h);
+}
+
+int tclip_paddle_run(const tclip_problem* pp, const float* x_q, const float* x_s, const int64_t* y_s, float lambd,
+                     float* u, float* v, float* w, int32_t* preds, void* workspace, size_t workspace_bytes,
+                     void* stream) {
+    if (int rc = check_problem(pp)) return rc;
+    const tclip_problem p = *pp;
+    if (!x_q || !x_s || !y_s || !u || !v || !w || !preds || !workspace) return fail(TCLIP_ERR_ARG, "null pointer argument");
+    if (p.n_support < 1) return fail(TCLIP_ERR_ARG, "PADDLE is a few-shot method: n_support must be positive");
+    size_t o_sup, o_cnt, o_cs, o_live, o_logit, o_rows, o_scratch, o_counts;
+    const size_t total = paddle_ws_parts(p, &o_sup, &o_cnt, &o_cs, &o_live, &o_logit, &o_rows, &o_scratch, &o_counts);
+    if (workspace_bytes < total) return fail(TCLIP_ERR_WORKSPACE, "workspace smaller than tclip_paddle_workspace_bytes()");
+    if (((uintptr_t)workspace & 255) != 0) return fail(TCLIP_ERR_WORKSPACE, "workspace must be 256-byte aligned");
+    hipStream_t st = (hipStream_t)stream;
+    char* ws = (char*)workspace;
+    const int Q = p.n_query, K = p.n_class, S = p.n_support, T = p.n_batches * p.tasks_per_batch, TK = T * K;
+    float* sup = (float*)(ws + o_sup);
+    float* cnt = (float*)(ws + o_cnt);
+    float* cs = (float*)(ws + o_cs);
+    uint8_t* live = (uint8_t*)(ws + o_live);
+    float* logit0 = (float*)(ws + o_logit);
+    int32_t* rows = (int32_t*)(ws + o_rows);
+    int32_t* scratch_rows = (int32_t*)(ws + o_scratch);
+    int32_t* counts = (int32_t*)(ws + o_counts);
+    // init (paddle.py:180-197): v = 0, prototypes = class means of the support set; every centroid moves every iteration
+    hipLaunchKernelGGL(k_fill, dim3(ew_grid(TK)), dim3(256), 0, st, v, 0.0f, (size_t)TK);
+    hipLaunchKernelGGL(k_support_stats, dim3(K, T), dim3(128), (size_t)S * sizeof(int), st, x_s, y_s, S, K, 0, sup, cnt);
+    hipLaunchKernelGGL(k_div_rows, dim3(ew_grid((size_t)TK * K)), dim3(256), 0, st, (const float*)sup, (const float*)cnt,
+                       (size_t)TK * K, K, w);
+    TCLIP_HIP(hipMemsetAsync(live, 1, (size_t)TK, st));
+    TCLIP_HIP(hipMemsetAsync(counts, 0, 256, st));
+    hipLaunchKernelGGL(k_build_rows, dim3((TK + 255) / 256), dim3(256), 0, st, (const uint8_t*)live, (const int32_t*)nullptr,
+                       TK, 0, scratch_rows, rows, counts);
+    for (int it = 0; it < p.iters; it++) {
+        // u_update (:105-116): softmax_k(-1/2 ||w_k - z_q||^2 + lambd v_k / Q)
+        dispatch_E<LaunchKmeansLogits>(K, TK > 16384 ? 16384 : TK, st, (const float*)w, x_q, (const int32_t*)rows,
+                                       (const int32_t*)(counts + 1), Q, K, -0.5f, 1.0f, logit0);
+        hipLaunchKernelGGL(k_softmax, dim3((T * Q * 16 + 255) / 256), dim3(256), 0, st, (const float*)logit0, (const float*)v,
+                           T * Q, Q, K, lambd, 0, 0, u, preds);
+        // v_update (:118-124) and w_update (:142-158)
+        hipLaunchKernelGGL(k_cluster_sizes, dim3((TK + 255) / 256), dim3(256), 0, st, (const float*)u, T, Q, K, 0, cs, live,
+                           v, (int32_t*)nullptr);
+        hipLaunchKernelGGL(k_mstats, dim3((K + 63) / 64, K, T), dim3(64), 0, st, (const float*)u, x_q, (const float*)cs,
+                           (const uint8_t*)live, (const float*)sup, (const float*)cnt, Q, K, w, 1);
     }
     TCLIP_HIP(hipGetLastError());
     return TCLIP_OK;

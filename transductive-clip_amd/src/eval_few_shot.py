@@ -7,12 +7,13 @@ import torch
 
 from src.methods.few_shot.em_dirichlet import EM_DIRICHLET
 from src.methods.few_shot.hard_em_dirichlet import HARD_EM_DIRICHLET
+from src.methods.few_shot.paddle import PADDLE
 from src.sampler_few_shot import CategoriesSampler_few_shot, SamplerQuery_few_shot, SamplerSupport_few_shot
 from src.task_generator_few_shot import relabel
 from src.utils import Logger, compute_confidence_interval
 from tclip_amd import engine, sharding
 
-_METHODS = {'EM_DIRICHLET': EM_DIRICHLET, 'HARD_EM_DIRICHLET': HARD_EM_DIRICHLET}
+_METHODS = {'EM_DIRICHLET': EM_DIRICHLET, 'HARD_EM_DIRICHLET': HARD_EM_DIRICHLET, 'PADDLE': PADDLE}
 
 
 class Evaluator_few_shot:
