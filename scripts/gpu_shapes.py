@@ -29,3 +29,26 @@ x, _ = synth.make_query_tasks(8, 1000, seed=5, k_eff=5); xs, ys = synth.make_sup
 x, xs, ys = x.cuda(), xs.cuda(), ys.squeeze(2).cuda()
 timed("K=1000 few-shot 4-shot soft, 1 batch x 8 tasks, 20x1000 (configs[4] shape)",
       lambda: engine.run_em_dirichlet(x, xs, ys, n_batches=1, iters=20, iter_mm=1000, lambd=200 * 75, hard=False))
+
+
+def timed_fn(label, fn, note):
+    fn(); torch.cuda.synchronize()
+    t = time.time(); fn(); torch.cuda.synchronize(); dt = time.time() - t
+    print(f"{label}: {dt * 1e3:.1f} ms  {note(dt)}", flush=True)
+
+
+T, K, Q = 1000, 397, 75
+x, _ = synth.make_query_tasks(T, K, seed=6); x = x.cuda()
+flop = lambda iters: iters * T * K * Q * K * 5.0          # distance (3 flop per term) + statistics (2 flop per term)
+timed_fn("SOFT_KMEANS K=397, 1000 tasks, 20 iterations (configs[2] second method)",
+         lambda: engine.run_soft_kmeans(x, iters=20, temperature=30),
+         lambda dt: f"{T / dt:.0f} tasks/s, {flop(20) / dt / 1e12:.2f} TFLOP/s fp32 of the two contractions")
+timed_fn("HARD_KMEANS K=397, 1000 tasks, 10 iterations",
+         lambda: engine.run_hard_kmeans(x, iters=10, n_batches=10),
+         lambda dt: f"{T / dt:.0f} tasks/s, {flop(10) / dt / 1e12:.2f} TFLOP/s")
+T, K = 1000, 100
+x, _ = synth.make_query_tasks(T, K, seed=6, k_eff=5); xs, ys = synth.make_support(T, K, 4, seed=6)
+x, xs, ys = x.cuda(), xs.cuda(), ys.squeeze(2).cuda()
+timed_fn("PADDLE K=100 4-shot, 1000 tasks, 20 iterations",
+         lambda: engine.run_paddle(x, xs, ys, iters=20, lambd=5.0),
+         lambda dt: f"{T / dt:.0f} tasks/s")

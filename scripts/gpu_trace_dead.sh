@@ -19,5 +19,9 @@ out = []
 for kind, us in seq[half:]:
     out.append(f"{kind}{us:.0f}")
 print(" ".join(out))
+# idle gaps between consecutive kernels of the (single) stream, steady state: last 60 kernels
+allk = [(int(r["Start_Timestamp"]), int(r["End_Timestamp"]), r["Kernel_Name"].split("(")[0][-14:]) for r in rows]
+tail = allk[-60:]
+print("gaps_us:", " ".join(f"{tail[i][2]}>{(tail[i + 1][0] - tail[i][1]) / 1e3:.1f}" for i in range(len(tail) - 1)))
 PY
 rm -rf $R/gpurun_out/trace_dead
