@@ -107,6 +107,13 @@ size_t tclip_soft_kmeans_workspace_bytes(const tclip_problem* p);
 int tclip_soft_kmeans_run(const tclip_problem* p, const float* x_q, float temperature, float* u, float* w,
                           int32_t* preds, void* workspace, size_t workspace_bytes, void* stream);
 
+/* EM_GAUSSIAN on probability features (reference: src/methods/zero_shot/em_gaussian.py:107-229):
+ * SOFT_KMEANS with the class-proportion term, u = softmax_k(T * (-1/2 ||w_k - z_q||^2) + lambd v_k / Q),
+ * v = log(mean_q u + eps) + 1 (p->lambd as for EM-Dirichlet: int(K/5) * n_query).  Same problem
+ * fields and workspace (tclip_soft_kmeans_workspace_bytes) as SOFT_KMEANS; v device [T,K] out. */
+int tclip_em_gaussian_run(const tclip_problem* p, const float* x_q, float temperature, float* u, float* v, float* w,
+                          int32_t* preds, void* workspace, size_t workspace_bytes, void* stream);
+
 /* HARD_KMEANS on probability features (reference: src/methods/zero_shot/hard_kmeans.py:26-35,
  * 128-152, 186-204): centroids = means of the members, zero for empty clusters;
  * u = one_hot(argmin_k softmax_k ||w_k - z_q||^2) (first minimum).  Same problem fields as

@@ -248,3 +248,32 @@ def run_paddle(x_q, x_s, y_s, *, n_class, iters, lambd):
         criterions.append((u.clone() - u).norm(dim=(1, 2)).mean(0))
     return {"u": u, "v": v, "w": w, "criterions": torch.stack(criterions), "argmax": torch.stack(argmax),
             "seconds": time.time() - t0}
+
+
+def run_em_gaussian(x_q, *, n_class, iters, temperature, lambd):
+    """EM_GAUSSIAN on probability features, the reference's torch op sequence
+    (src/methods/zero_shot/em_gaussian.py:107-229): SOFT_KMEANS plus the class-proportion term,
+    u = softmax_k(T * (-1/2 ||w_k - z_q||^2) + lambd v_k / Q), v = log(mean_q u + eps) + 1.
+    Returns dict(u, v, w, criterions, argmax (iters,N,Q), seconds); the logged criterion is 0."""
+    query = x_q.clone().float()
+    n_task, n_query = query.shape[0], query.shape[1]
+    t0 = time.time()
+    v = torch.zeros(n_task, n_class)
+    u = query.clone()
+    num = (query.unsqueeze(2) * u.unsqueeze(3)).sum(1)
+    den = u.sum(1).clamp(min=EPS)
+    w = num.div_(den.unsqueeze(2))
+    criterions, argmax = [], []
+    for _ in range(iters):
+        num = (query.unsqueeze(2) * u.unsqueeze(3)).sum(1)
+        den = u.sum(1).clamp(min=EPS)
+        live = u.sum(1).unsqueeze(-1) > EPS
+        w = num.div_(den.unsqueeze(2)) * live + (w * (1 - 1 * live))
+        diff = w.unsqueeze(1) - query.unsqueeze(2)
+        logits = -1 / 2 * (diff.square_()).sum(dim=-1)
+        u = (temperature * logits + lambd * v.unsqueeze(1) / n_query).softmax(2)
+        argmax.append(u.argmax(2).clone())
+        v = torch.log(u.sum(1) / u.size(1) + EPS) + 1
+        criterions.append((u.clone() - u).norm(dim=(1, 2)).mean(0))
+    return {"u": u, "v": v, "w": w, "criterions": torch.stack(criterions), "argmax": torch.stack(argmax),
+            "seconds": time.time() - t0}

@@ -54,9 +54,10 @@ def load_reference_classes():
     from src.methods.zero_shot.soft_kmeans import SOFT_KMEANS as SKM
     from src.methods.zero_shot.hard_kmeans import HARD_KMEANS as HKM
     from src.methods.few_shot.paddle import PADDLE
+    from src.methods.zero_shot.em_gaussian import EM_GAUSSIAN as EMG
     sys.path.pop(0)
     return {"zs_soft": ZS, "zs_hard": ZSH, "fs_soft": FS, "fs_hard": FSH, "zs_skm": SKM, "zs_hkm": HKM,
-            "fs_paddle": PADDLE}
+            "fs_paddle": PADDLE, "zs_emg": EMG}
 
 
 # PADDLE's lambd is a tunable float (paddle.yaml: 0.0); the fixtures also use a value that makes the
@@ -85,6 +86,10 @@ SMALL = {
     "zs_hkm_K37_N6": ("zs_hkm", 37, 6, 20, 0, 2021, True),
     "zs_hkm_K100_N4": ("zs_hkm", 100, 4, 20, 0, 2022, True),
     "zs_hkm_K397_N2": ("zs_hkm", 397, 2, 20, 0, 2023, True),
+    "zs_emg_K10_N4": ("zs_emg", 10, 4, 20, 0, 2020, True),
+    "zs_emg_K37_N6": ("zs_emg", 37, 6, 20, 0, 2021, True),
+    "zs_emg_K100_N4": ("zs_emg", 100, 4, 20, 0, 2022, True),
+    "zs_emg_K397_N1": ("zs_emg", 397, 1, 20, 0, 2023, True),
     "fs_paddle_K10_N4_s4": ("fs_paddle", 10, 4, 20, 4, 2020, True),
     "fs_paddle_K37_N3_s2": ("fs_paddle", 37, 3, 20, 2, 2021, True),
     "fs_paddle_K100_N3_s1": ("fs_paddle", 100, 3, 20, 1, 2022, True),
@@ -129,7 +134,7 @@ def run_case(name, spec, classes):
             norm_vals.append(float(r))
         return r
 
-    is_skm = kind in ("zs_skm", "zs_hkm", "fs_paddle")      # k-means family: no MM loop, the centroids stand in for alpha
+    is_skm = kind in ("zs_skm", "zs_hkm", "fs_paddle", "zs_emg")      # k-means family: no MM loop, the centroids stand in for alpha
     real_update_alpha = None if is_skm else m.update_alpha
 
     def traced_update_alpha(alpha_0, y_cst):

@@ -1482,12 +1482,12 @@ size_t tclip_soft_kmeans_workspace_bytes(const tclip_problem* p) {
     return kmeans_ws_parts(*p, &a, &b, &c, &d, &e, &f, &g);
 }
 
-int tclip_soft_kmeans_run(const tclip_problem* pp, const float* x_q, float temperature, float* u, float* w,
-                          int32_t* preds, void* workspace, size_t workspace_bytes, void* stream) {
-    if (int rc = check_problem(pp)) return rc;
-    const tclip_problem p = *pp;
+// SOFT_KMEANS (v == nullptr) and EM_GAUSSIAN (v given: the class-proportion term lambd * v / Q in the
+// softmax and the v update of em_gaussian.py:129-143) share everything else.
+static int soft_kmeans_core(const tclip_problem& p, const float* x_q, float temperature, float* v, float* u, float* w,
+                            int32_t* preds, void* workspace, size_t workspace_bytes, void* stream, const char* who) {
     if (!x_q || !u || !w || !preds || !workspace) return fail(TCLIP_ERR_ARG, "null pointer argument");
-    if (p.n_support != 0) return fail(TCLIP_ERR_ARG, "SOFT_KMEANS is a zero-shot method: n_support must be 0");
+    if (p.n_support != 0) return fail(TCLIP_ERR_ARG, "%s is a zero-shot method: n_support must be 0", who);
     size_t o_cs, o_live, o_ones, o_logit, o_rows, o_scratch, o_counts;
     const size_t total = kmeans_ws_parts(p, &o_cs, &o_live, &o_ones, &o_logit, &o_rows, &o_scratch, &o_counts);
     if (workspace_bytes < total) return fail(TCLIP_ERR_WORKSPACE, "workspace smaller than tclip_soft_kmeans_workspace_bytes()");
@@ -1505,6 +1505,7 @@ int tclip_soft_kmeans_run(const tclip_problem* pp, const float* x_q, float tempe
     int32_t* counts = (int32_t*)(ws + o_counts);
     hipLaunchKernelGGL(k_copy, dim3(ew_grid(TQK)), dim3(256), 0, st, x_q, u, TQK);          // u = z
     TCLIP_HIP(hipMemsetAsync(ones, 1, (size_t)TK, st));
+    if (v) hipLaunchKernelGGL(k_fill, dim3(ew_grid(TK)), dim3(256), 0, st, v, 0.0f, (size_t)TK);
     // w_init: every centroid = u^T z / clamp(sum u)                             (soft_kmeans.py:137-149)
     hipLaunchKernelGGL(k_cluster_sizes, dim3((TK + 255) / 256), dim3(256), 0, st, (const float*)u, T, Q, K, 1, cs, live,
                        (float*)nullptr, (int32_t*)nullptr);
@@ -1512,8 +1513,9 @@ int tclip_soft_kmeans_run(const tclip_problem* pp, const float* x_q, float tempe
                        (const uint8_t*)ones, (const float*)nullptr, (const float*)nullptr, Q, K, w);
     for (int it = 0; it < p.iters; it++) {
         // w_update: live clusters get the new mean, empty ones keep their centroid   (:151-168)
+        // EM_GAUSSIAN: the same pass over u also yields v of the previous iteration's v_update (v stays 0 before the first)
         hipLaunchKernelGGL(k_cluster_sizes, dim3((TK + 255) / 256), dim3(256), 0, st, (const float*)u, T, Q, K, 1, cs,
-                           live, (float*)nullptr, (int32_t*)nullptr);
+                           live, it > 0 ? v : (float*)nullptr, (int32_t*)nullptr);
         hipLaunchKernelGGL(k_mstats, dim3((K + 63) / 64, K, T), dim3(64), 0, st, (const float*)u, x_q, (const float*)cs,
                            (const uint8_t*)live, (const float*)nullptr, (const float*)nullptr, Q, K, w);
         // distances only for centroids that moved (all of them in the first iteration)
@@ -1523,10 +1525,26 @@ int tclip_soft_kmeans_run(const tclip_problem* pp, const float* x_q, float tempe
         dispatch_E<LaunchKmeansLogits>(K, TK > 16384 ? 16384 : TK, st, (const float*)w, x_q, (const int32_t*)rows,
                                        (const int32_t*)(counts + 1), Q, K, -0.5f, temperature, logit0);
         hipLaunchKernelGGL(k_softmax, dim3((T * Q * 16 + 255) / 256), dim3(256), 0, st, (const float*)logit0,
-                           (const float*)nullptr, T * Q, Q, K, 0.0f, 0, 0, u, preds);
+                           (const float*)v, T * Q, Q, K, (float)p.lambd, 0, 0, u, preds);
     }
+    if (v)      // the last v_update
+        hipLaunchKernelGGL(k_cluster_sizes, dim3((TK + 255) / 256), dim3(256), 0, st, (const float*)u, T, Q, K, 1, cs, live,
+                           v, (int32_t*)nullptr);
     TCLIP_HIP(hipGetLastError());
     return TCLIP_OK;
+}
+
+int tclip_soft_kmeans_run(const tclip_problem* pp, const float* x_q, float temperature, float* u, float* w,
+                          int32_t* preds, void* workspace, size_t workspace_bytes, void* stream) {
+    if (int rc = check_problem(pp)) return rc;
+    return soft_kmeans_core(*pp, x_q, temperature, nullptr, u, w, preds, workspace, workspace_bytes, stream, "SOFT_KMEANS");
+}
+
+int tclip_em_gaussian_run(const tclip_problem* pp, const float* x_q, float temperature, float* u, float* v, float* w,
+                          int32_t* preds, void* workspace, size_t workspace_bytes, void* stream) {
+    if (int rc = check_problem(pp)) return rc;
+    if (!v) return fail(TCLIP_ERR_ARG, "null pointer argument");
+    return soft_kmeans_core(*pp, x_q, temperature, v, u, w, preds, workspace, workspace_bytes, stream, "EM_GAUSSIAN");
 }
 
 size_t tclip_hard_kmeans_workspace_bytes(const tclip_problem* p) {

@@ -25,6 +25,7 @@ _SIGNATURES = {
     "tclip_gather_rows": (ctypes.c_int, [_P, ctypes.c_int64, ctypes.c_int32, _P, ctypes.c_int64, _P, _P]),
     "tclip_soft_kmeans_workspace_bytes": (ctypes.c_size_t, [ctypes.POINTER(Problem)]),
     "tclip_soft_kmeans_run": (ctypes.c_int, [ctypes.POINTER(Problem), _P, ctypes.c_float, _P, _P, _P, _P, ctypes.c_size_t, _P]),
+    "tclip_em_gaussian_run": (ctypes.c_int, [ctypes.POINTER(Problem), _P, ctypes.c_float, _P, _P, _P, _P, _P, ctypes.c_size_t, _P]),
     "tclip_paddle_workspace_bytes": (ctypes.c_size_t, [ctypes.POINTER(Problem)]),
     "tclip_paddle_run": (ctypes.c_int, [ctypes.POINTER(Problem), _P, _P, _P, ctypes.c_float, _P, _P, _P, _P, _P, ctypes.c_size_t, _P]),
     "tclip_hard_kmeans_workspace_bytes": (ctypes.c_size_t, [ctypes.POINTER(Problem)]),
