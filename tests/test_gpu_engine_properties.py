@@ -49,6 +49,23 @@ def test_engine_equals_cpu_oracle_on_fresh_inputs(K, N, B, hard, few):
             assert (res.criterions[b].cpu().numpy() == 0).all()
 
 
+@pytest.mark.parametrize("K", [150, 230, 300, 500, 620, 750, 880, 1024])
+def test_every_row_width_instantiation(K):
+    """One case per register count of the MM kernels that no fixture covers (E = 6, 8, 10, 16, 20,
+    24, 28 and the full 32), short schedule, against the C++ oracle."""
+    from oracle import c_oracle
+    from tclip_amd import engine, synth
+    N, iters, iter_mm, lambd = 2, 2, 60, int(K / 5) * 75
+    x_q, _ = synth.make_query_tasks(N, K, seed=400 + K)
+    res = engine.run_em_dirichlet(x_q.cuda(), n_batches=1, iters=iters, iter_mm=iter_mm, lambd=lambd, hard=False)
+    torch.cuda.synchronize()
+    ref = c_oracle.run(x_q.numpy(), iters=iters, iter_mm=iter_mm, lambd=lambd, hard=False)
+    assert np.array_equal(res.mm_iters[0].cpu().numpy(), ref["mm_iters"])
+    assert np.array_equal(res.alpha.cpu().numpy(), ref["alpha"])
+    assert np.array_equal(res.u.cpu().numpy(), ref["u"])
+    assert np.array_equal(res.preds.cpu().numpy(), ref["argmax"][-1].astype(np.int32))
+
+
 @pytest.mark.parametrize("K,N", [(12, 3), (40, 4)])
 def test_nan_in_one_task_leaves_the_others_exact(K, N):
     """A NaN feature poisons its own task (as in the reference) and pushes every block that holds
