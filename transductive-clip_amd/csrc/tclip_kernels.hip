@@ -508,9 +508,9 @@ __global__ __launch_bounds__(256, (E > 8 ? 3 : TCLIP_MM_WAVES_SMALL)) void k_mm_
 // both; counts are double-buffered and slices are wave-private outside the dense pass, so a wave
 // that runs ahead into the next iteration cannot disturb one that is still picking up results.
 // `bad` is raised by a wave that holds an argument outside the fast domain.
-struct QueueCtl { int count[2][4]; int bad; };
+struct QueueCtl { int count[2][8]; int bad; };
 
-template <int E>
+template <int E, int W>
 __device__ __forceinline__ void mm_iterate_block(float (&beta)[E], const RowY<E>& yv, int K, int lane, bool active,
                                                  const LogTabEntry* tab, float* queue, QueueCtl* ctl, int turn,
                                                  bool measure, double& num, double& den) {
@@ -541,8 +541,11 @@ __device__ __forceinline__ void mm_iterate_block(float (&beta)[E], const RowY<E>
         if (!wave_ok) ctl->bad = 1;
     }
     __syncthreads();
-    const int c0 = ctl->count[turn & 1][0], c1 = ctl->count[turn & 1][1], c2 = ctl->count[turn & 1][2];
-    const int n_big = c0 + c1 + c2 + ctl->count[turn & 1][3];
+    int before[W + 1];                                          // entries queued by the waves in front of wave w
+    before[0] = 0;
+#pragma unroll
+    for (int w = 0; w < W; w++) before[w + 1] = before[w] + ctl->count[turn & 1][w];
+    const int n_big = before[W];
     const bool bad = ctl->bad != 0;
     if (__builtin_expect(bad, 0)) {                             // NaN / inf / out of range somewhere in the block
         __syncthreads();                                        // everyone has seen the flag
@@ -566,11 +569,12 @@ __device__ __forceinline__ void mm_iterate_block(float (&beta)[E], const RowY<E>
     }
     // phase B: dense evaluation, results overwrite the queue.  Usually one pass of one wave covers
     // the whole queue; the wave that takes the first 64 entries rotates with the iteration so that
-    // this work spreads over the four SIMDs of the CU (wave w of every block sits on SIMD w).
-    for (int start = ((wave + turn) & 3) * 64; start < n_big; start += 256) {
+    // this work spreads over the four SIMDs of the CU (wave w of every block sits on SIMD w % 4).
+    for (int start = ((wave + turn) & (W - 1)) * 64; start < n_big; start += 64 * W) {
         const int j = start + lane64;                          // j-th entry of the block, slices in wave order
-        const int w = (j >= c0) + (j >= c0 + c1) + (j >= c0 + c1 + c2);
-        const int at = w * (64 * E) + j - (w == 0 ? 0 : w == 1 ? c0 : w == 2 ? c0 + c1 : c0 + c1 + c2);
+        int at = j;
+#pragma unroll
+        for (int w = 1; w < W; w++) at += j >= before[w] ? 64 * E - (before[w] - before[w - 1]) : 0;
         const float v = j < n_big ? queue[at] : 8.0f;
         const float r = lgamma_sleef_ge23<true>(v);
         if (j < n_big) queue[at] = r;
@@ -582,16 +586,19 @@ __device__ __forceinline__ void mm_iterate_block(float (&beta)[E], const RowY<E>
     mm_apply_updates<E>(beta, yv, K, lane, psi_s, tab, slice, 0, measure, num, den);
 }
 
-template <int E>
-__global__ __launch_bounds__(256, (E > 8 ? 3 : TCLIP_MM_WAVES_SMALL)) void k_mm_live(MMArgs a) {
+#ifndef TCLIP_MM_BLOCK_WAVES
+#define TCLIP_MM_BLOCK_WAVES 4        // waves (= pairs of rows) per block of k_mm_live for E <= 8
+#endif
+template <int E, int W>
+__global__ __launch_bounds__(64 * W, (E > 8 ? 3 : TCLIP_MM_WAVES_SMALL)) void k_mm_live(MMArgs a) {
     __shared__ LogTabEntry tab[16];
-    __shared__ float queue[256 * E];
+    __shared__ float queue[64 * W * E];
     __shared__ QueueCtl ctl;
     if (threadIdx.x == 0) ctl.bad = 0;
     load_log_table(tab);
     const int lane = threadIdx.x & (kGroup - 1);
     const int group = threadIdx.x / kGroup;
-    constexpr int kRows = 256 / kGroup;
+    constexpr int kRows = 2 * W;
     int turn = 0;
     const int n = *a.n_rows;
     const int K = a.K;
@@ -610,7 +617,7 @@ __global__ __launch_bounds__(256, (E > 8 ? 3 : TCLIP_MM_WAVES_SMALL)) void k_mm_
         }
         double num = 0.0, den = 0.0;
         for (int l = a.l0; l <= a.l1; l++)
-            mm_iterate_block<E>(beta, yv, K, lane, active, tab, queue, &ctl, turn++, a.has_check && l == a.l1, num, den);
+            mm_iterate_block<E, W>(beta, yv, K, lane, active, tab, queue, &ctl, turn++, a.has_check && l == a.l1, num, den);
         if (!active) continue;
 #pragma unroll
         for (int e = 0; e < E; e++) {
@@ -1192,7 +1199,12 @@ template <int E> struct LaunchMM {
     static void run(int grid, hipStream_t st, MMArgs a) { hipLaunchKernelGGL(k_mm_chunk<E>, dim3(grid), dim3(256), 0, st, a); }
 };
 template <int E> struct LaunchMMLive {
-    static void run(int grid, hipStream_t st, MMArgs a) { hipLaunchKernelGGL(k_mm_live<E>, dim3(grid), dim3(256), 0, st, a); }
+    static constexpr int kWaves = E > 8 ? 4 : TCLIP_MM_BLOCK_WAVES;
+    static void run(int rows, hipStream_t st, MMArgs a) {
+        int grid = (rows + 2 * kWaves - 1) / (2 * kWaves);
+        if (grid > 256 * 16) grid = 256 * 16;
+        hipLaunchKernelGGL((k_mm_live<E, kWaves>), dim3(grid), dim3(64 * kWaves), 0, st, a);
+    }
 };
 template <int E> struct LaunchRowConsts {
     static void run(int grid, hipStream_t st, const float* alpha, const int32_t* rows, const int32_t* n, int K, float* rowc) {
@@ -1312,7 +1324,7 @@ static int enqueue_batches(const tclip_problem& p, const float* x_q, const float
             hipEvent_t e0 = g_prof.on ? prof_event() : nullptr, e1 = g_prof.on ? prof_event() : nullptr;
             if (e0 && e1) TCLIP_HIP(hipEventRecord(e0, st));
             a.rows = live_rows; a.n_rows = counts + 1;
-            dispatch_E<LaunchMMLive>(K, grid, st, a);
+            dispatch_E<LaunchMMLive>(K, TK, st, a);
             if (e0 && e1) TCLIP_HIP(hipEventRecord(e1, st));    // the instrumentation covers k_mm_live only
             if (zs && a.has_check) {          // dead rows only matter through their stop-test terms
                 a.rows = mm_rows; a.n_rows = counts; a.work_counter = nullptr;
