@@ -570,7 +570,7 @@ __device__ __forceinline__ void mm_iterate_block(float (&beta)[E], const RowY<E>
     // phase B: dense evaluation, results overwrite the queue.  Usually one pass of one wave covers
     // the whole queue; the wave that takes the first 64 entries rotates with the iteration so that
     // this work spreads over the four SIMDs of the CU (wave w of every block sits on SIMD w % 4).
-    for (int start = ((wave + turn) & (W - 1)) * 64; start < n_big; start += 64 * W) {
+    for (int start = ((wave + turn) % W) * 64; start < n_big; start += 64 * W) {
         const int j = start + lane64;                          // j-th entry of the block, slices in wave order
         int at = j;
 #pragma unroll
