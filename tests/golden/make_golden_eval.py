@@ -61,14 +61,21 @@ def main():
     sys.path.pop(0)
     torch.set_num_threads(min(8, os.cpu_count() or 1))
     seed = 2020
-    for kind, hard in (("zs", False), ("zs", True), ("fs", False)):
+    only = set(sys.argv[1:])
+    cases = [("zs", False, None), ("zs", True, None), ("fs", False, None),
+             ("zs", False, "HARD_KMEANS"), ("zs", False, "EM_GAUSSIAN"), ("zs", False, "SOFT_KMEANS"), ("fs", False, "PADDLE")]
+    for kind, hard, other in cases:
         K = 10
-        args = Args(iter=10 if hard else 20, iter_mm=1000, num_classes_test=K, n_class=K, n_query=75, k_eff=5, T=30,
-                    use_softmax_feature=True, graph_matching=True, shots=2, number_tasks=20, batch_size=10,
-                    name_method="HARD_EM_DIRICHLET" if hard else "EM_DIRICHLET", used_test_set="test", tunable=False,
-                    method="hard_em_dirichlet" if hard else "em_dirichlet", dataset="synthetic")
+        method = other or ("HARD_EM_DIRICHLET" if hard else "EM_DIRICHLET")
+        if only and method not in only:
+            continue
+        args = Args(iter=10 if (hard or other == "HARD_KMEANS") else 20, iter_mm=1000, num_classes_test=K, n_class=K,
+                    n_query=75, k_eff=5, T=30, use_softmax_feature=True, graph_matching=True, shots=2, number_tasks=20,
+                    batch_size=10, name_method=method, used_test_set="test", tunable=False, lambd=5.0,
+                    method=method.lower(), dataset="synthetic")
         feats, labels = synth.make_feature_table(K, 40, seed=seed)
-        out = {"kind": kind, "hard": hard, "K": K, "seed": seed, "rows_per_class": 40,
+        out = {"kind": kind, "hard": hard, "K": K, "seed": seed, "rows_per_class": 40, "method": method,
+               "iters": args.iter, "lambd": args.lambd,
                "number_tasks": 20, "batch_size": 10, "shots": 2}
         seed_all(seed)
         if kind == "zs":
@@ -91,7 +98,7 @@ def main():
             out["support_idx"] = torch.stack(s).numpy().reshape(2, 10, -1)
             out["support_rows_per_class"] = 16
         out["mean_accuracy"] = np.float64(acc)
-        name = f"eval_{kind}_{'hard' if hard else 'soft'}_K10"
+        name = f"eval_{kind}_{'hard' if hard else 'soft'}_K10" if other is None else f"eval_{kind}_{other.lower()}_K10"
         np.savez_compressed(os.path.join(HERE, name + ".npz"), **out)
         print(name, "acc", acc, "time", t, {k: getattr(v, "shape", v) for k, v in out.items()})
 

@@ -166,18 +166,21 @@ def test_full_size_properties_k100_batch100():
     assert ((hard.u == 0) | (hard.u == 1)).all() and (hard.u.sum(-1) == 1).all()
 
 
-@pytest.mark.parametrize("name", ["eval_zs_soft_K10", "eval_zs_hard_K10", "eval_fs_soft_K10"])
+@pytest.mark.parametrize("name", ["eval_zs_soft_K10", "eval_zs_hard_K10", "eval_fs_soft_K10", "eval_zs_soft_kmeans_K10",
+                                  "eval_zs_hard_kmeans_K10", "eval_zs_em_gaussian_K10", "eval_fs_paddle_K10"])
 def test_task_batch_loop_matches_reference(name):
     """evaluate_tasks on the seeded synthetic table: the reference's mean accuracy (fixtures made
-    by running the reference's Evaluator_*.evaluate_tasks)."""
+    by running the reference's Evaluator_*.evaluate_tasks), for every method behind the boundary."""
     from src.utils import CfgNode
     from tclip_amd import synth
     g = np.load(os.path.join(GOLDEN, name + ".npz"))
     hard, K = bool(g["hard"]), int(g["K"])
-    a = CfgNode(iter=10 if hard else 20, iter_mm=1000, num_classes_test=K, n_class=K, n_query=75, k_eff=5, T=30,
+    method = str(g["method"]) if "method" in g.files else ("HARD_EM_DIRICHLET" if hard else "EM_DIRICHLET")
+    iters = int(g["iters"]) if "iters" in g.files else (10 if hard else 20)
+    a = CfgNode(iter=iters, iter_mm=1000, num_classes_test=K, n_class=K, n_query=75, k_eff=5, T=30,
                 use_softmax_feature=True, graph_matching=True, shots=int(g["shots"]), number_tasks=int(g["number_tasks"]),
-                batch_size=int(g["batch_size"]), name_method="HARD_EM_DIRICHLET" if hard else "EM_DIRICHLET",
-                used_test_set="test")
+                batch_size=int(g["batch_size"]), name_method=method, used_test_set="test",
+                lambd=float(g["lambd"]) if "lambd" in g.files else 0.0)
     feats, labels = synth.make_feature_table(K, int(g["rows_per_class"]), seed=int(g["seed"]))
     random.seed(int(g["seed"]))
     torch.manual_seed(int(g["seed"]))
