@@ -290,6 +290,11 @@ struct RowY {
     }
 };
 
+// Number of set bits of a wave mask below the calling lane (v_mbcnt_lo/hi: two instructions).
+__device__ __forceinline__ int lanes_below(unsigned long long m) {
+    return (int)__builtin_amdgcn_mbcnt_hi((unsigned)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m, 0u));
+}
+
 // Phase C of one MM iteration: every element's digamma, the cheap lgamma branch, the pick-up of
 // the large-argument results queued at `queue[base...]` in ballot order, and the update algebra.
 // Elements are advanced two at a time on the packed fp32 pipe (tclip_pk.h); an odd last one
@@ -301,17 +306,16 @@ template <int E>
 __device__ __forceinline__ void mm_apply_updates(float (&beta)[E], const RowY<E>& yv, int K, int lane, float psi_s,
                                                  const LogTabEntry* tab, const float* queue, int base, bool measure,
                                                  double& num, double& den) {
-    const unsigned long long lt_mask = (1ull << (threadIdx.x & 63)) - 1ull;
 #pragma unroll
     for (int p = 0; p < (TCLIP_MM_PACKED ? E / 2 : 0); p++) {
         const int e = 2 * p;
         const f2 a{beta[e], beta[e + 1]};
         const bool big0 = a.x + 1.0f >= 2.3f, big1 = a.y + 1.0f >= 2.3f;
         const unsigned long long m0 = __ballot(big0);
-        const float lg0 = big0 ? queue[base + __popcll(m0 & lt_mask)] : 0.0f;
+        const float lg0 = big0 ? queue[base + lanes_below(m0)] : 0.0f;
         base += __popcll(m0);
         const unsigned long long m1 = __ballot(big1);
-        const float lg1 = big1 ? queue[base + __popcll(m1 & lt_mask)] : 0.0f;
+        const float lg1 = big1 ? queue[base + lanes_below(m1)] : 0.0f;
         base += __popcll(m1);
         const f2 nb = pk_mm_update(a, f2{yv.get(e), yv.get(e + 1)}, pk(psi_s), f2{lg0, lg1}, tab);
         const bool ok0 = e * kGroup + lane < K, ok1 = (e + 1) * kGroup + lane < K;
@@ -329,7 +333,7 @@ __device__ __forceinline__ void mm_apply_updates(float (&beta)[E], const RowY<E>
         const float x1 = a + 1.0f;
         const bool big = x1 >= 2.3f;
         const unsigned long long m = __ballot(big);
-        const float lg_big = big ? queue[base + __popcll(m & lt_mask)] : 0.0f;
+        const float lg_big = big ? queue[base + lanes_below(m)] : 0.0f;
         base += __popcll(m);
         bool sure;
         float lg_small = lgamma_sleef_1_23_f64(big ? 2.0f : x1, sure);
@@ -370,7 +374,6 @@ __device__ __forceinline__ void mm_iterate(float (&beta)[E], const RowY<E>& yv, 
         return;
     }
     const float psi_s = digamma_pos_f32(s, tab);   // row sums are mostly >= 10: the recurrence loop is rarely entered
-    const unsigned long long lt_mask = (1ull << (threadIdx.x & 63)) - 1ull;
     // phase A: queue the arguments of the expensive lgamma branch
     int n_big = 0;
 #pragma unroll
@@ -378,14 +381,14 @@ __device__ __forceinline__ void mm_iterate(float (&beta)[E], const RowY<E>& yv, 
         const float x1 = beta[e] + 1.0f;
         const bool big = x1 >= 2.3f;
         const unsigned long long m = __ballot(big);
-        if (big) queue[n_big + __popcll(m & lt_mask)] = x1;
+        if (big) queue[n_big + lanes_below(m)] = x1;
         n_big += __popcll(m);
     }
     __builtin_amdgcn_wave_barrier();
     // phase B: dense evaluation by the ACTIVE lanes (one half of the wave may be idle), results
     // overwrite the queue
     const unsigned long long active = __ballot(true);
-    const int rank = __popcll(active & lt_mask), n_active = __popcll(active);
+    const int rank = lanes_below(active), n_active = __popcll(active);
     for (int start = 0; start < n_big; start += n_active) {
         const int idx = start + rank;
         const float v = idx < n_big ? queue[idx] : 8.0f;
@@ -515,7 +518,6 @@ __device__ __forceinline__ void mm_iterate_block(float (&beta)[E], const RowY<E>
                                                  const LogTabEntry* tab, float* queue, QueueCtl* ctl, int turn,
                                                  bool measure, double& num, double& den) {
     const int wave = threadIdx.x >> 6, lane64 = threadIdx.x & 63;
-    const unsigned long long lt_mask = (1ull << lane64) - 1ull;
     float s = 16.0f;
     bool in_domain = true;
     if (active) {
@@ -532,7 +534,7 @@ __device__ __forceinline__ void mm_iterate_block(float (&beta)[E], const RowY<E>
         const float x1 = beta[e] + 1.0f;
         const bool big = active && x1 >= 2.3f;
         const unsigned long long m = __ballot(big);
-        if (big) slice[idx + __popcll(m & lt_mask)] = x1;
+        if (big) slice[idx + lanes_below(m)] = x1;
         idx += __popcll(m);
     }
     const bool wave_ok = __all(in_domain);
