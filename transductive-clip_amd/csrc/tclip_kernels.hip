@@ -403,11 +403,14 @@ __device__ __forceinline__ void mm_iterate(float (&beta)[E], const RowY<E>& yv, 
 
 constexpr int kMaxCycle = 64;  // longest limit cycle looked for on dead rows (periods up to 20 seen at K=1000)
 
+#ifndef TCLIP_MM_WAVES_LARGE
+#define TCLIP_MM_WAVES_LARGE 3     // waves per SIMD requested for long rows (E > 8)
+#endif
 #ifndef TCLIP_MM_WAVES_SMALL
 #define TCLIP_MM_WAVES_SMALL 4     // waves per SIMD requested for short rows (E <= 8)
 #endif
 template <int E>
-__global__ __launch_bounds__(256, (E > 8 ? 3 : TCLIP_MM_WAVES_SMALL)) void k_mm_chunk(MMArgs a) {
+__global__ __launch_bounds__(256, (E > 8 ? TCLIP_MM_WAVES_LARGE : TCLIP_MM_WAVES_SMALL)) void k_mm_chunk(MMArgs a) {
     __shared__ LogTabEntry tab[16];
     __shared__ double cyc[8][kMaxCycle][2];
     __shared__ float lg_queue[4][64 * E];             // per wave: arguments / results of the large-x lgamma
@@ -592,7 +595,7 @@ __device__ __forceinline__ void mm_iterate_block(float (&beta)[E], const RowY<E>
 #define TCLIP_MM_BLOCK_WAVES 4        // waves (= pairs of rows) per block of k_mm_live for E <= 8
 #endif
 template <int E, int W>
-__global__ __launch_bounds__(64 * W, (E > 8 ? 3 : TCLIP_MM_WAVES_SMALL)) void k_mm_live(MMArgs a) {
+__global__ __launch_bounds__(64 * W, (E > 8 ? TCLIP_MM_WAVES_LARGE : TCLIP_MM_WAVES_SMALL)) void k_mm_live(MMArgs a) {
     __shared__ LogTabEntry tab[16];
     __shared__ float queue[64 * W * E];
     __shared__ QueueCtl ctl;
