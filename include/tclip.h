@@ -158,6 +158,12 @@ int tclip_profile_enable(int on);
 int tclip_profile_collect(double* mm_busy_ms, double* mm_launch_ms_sum, int64_t* mm_launches,
                           int64_t* element_updates);
 
+/* Dead rows are spared the rest of their schedule once a limit-cycle probe (run after each of the
+ * first `chunks` 50-iteration chunks) finds them on a cycle of the fp32 map - an exact shortcut.
+ * For tests: 0 disables the probe (every dead row iterates its whole schedule once), negative
+ * restores the default.  Process-wide; results do not depend on it. */
+int tclip_debug_set_probe_chunks(int32_t chunks);
+
 /* Device self-test (used by tests/test_gpu_primitives.py).  out host [14]:
  *   [0] 1/x: fast exact reciprocal vs IEEE quotient, every float of a binade at 3 exponents
  *   [1] a/b: 2^29 operand pairs            [2] fused digamma(a+1), digamma of row sums vs generic

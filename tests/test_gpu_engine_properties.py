@@ -66,6 +66,29 @@ def test_every_row_width_instantiation(K):
     assert np.array_equal(res.preds.cpu().numpy(), ref["argmax"][-1].astype(np.int32))
 
 
+@pytest.mark.parametrize("K,N,B", [(397, 12, 2), (1000, 6, 2)])
+def test_limit_cycle_shortcut_is_exact(K, N, B):
+    """The dead rows' limit-cycle shortcut must not change anything: no probe at all, a probe after
+    chunk 0 only, and probes after every chunk give identical alpha, u and MM counts (dead rows that
+    reach their cycle late are only caught by the later probes; a wrong cache entry shows up as an
+    early batch stop in a LATER outer iteration)."""
+    from tclip_amd import engine, synth
+    x_q, _ = synth.make_query_tasks(B * N, K, seed=50 + K)
+    x = x_q.cuda()
+    runs = []
+    try:
+        for chunks in (0, 1, 19, 19):
+            engine.debug_set_probe_chunks(chunks)
+            r = engine.run_em_dirichlet(x, n_batches=B, iters=5, iter_mm=1000, lambd=int(K / 5) * 75, hard=False)
+            torch.cuda.synchronize()
+            runs.append(r)
+    finally:
+        engine.debug_set_probe_chunks(-1)
+    for r in runs[1:]:
+        assert torch.equal(r.mm_iters, runs[0].mm_iters)
+        assert torch.equal(r.alpha, runs[0].alpha) and torch.equal(r.u, runs[0].u)
+
+
 @pytest.mark.parametrize("K,N", [(12, 3), (40, 4)])
 def test_nan_in_one_task_leaves_the_others_exact(K, N):
     """A NaN feature poisons its own task (as in the reference) and pushes every block that holds

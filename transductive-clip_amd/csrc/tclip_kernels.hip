@@ -8,7 +8,8 @@
 //                     contributions are not cached yet
 //   k_mm_live x20     <=50 majorize-minimize iterations per launch for the live rows, alpha rows
 //                     register-resident, large-argument lgamma work queued block-wide in LDS
-//   k_mm_chunk x20    the same for the listed dead rows (per-wave queue, limit-cycle detection)
+//   k_mm_live<dead>   the same for the listed dead rows (y = -10, iterate kept in a scratch copy),
+//   k_mm_probe        after chunk 0: limit-cycle detection that spares them the remaining chunks
 //   k_mm_decide x20   batch-global stop test on device, no host round trip          (:157-177)
 //   k_row_consts      lgamma(sum alpha) - sum lgamma(alpha) for rows that changed  (:35-36)
 //   k_logits          (alpha-1) . log z contraction for rows that changed          (:37-38)
@@ -218,7 +219,7 @@ __global__ void k_mstats(const float* __restrict__ u, const float* __restrict__ 
 // ------------------------------------------------------------------------------------------
 // Row lists for one outer iteration.  live_rows: rows whose alpha will change (k_mm_live iterates
 // them, and their E-step terms must be recomputed); dead_rows: dead rows whose cached stop-test
-// terms are incomplete (k_mm_chunk iterates them).  Order inside the lists is irrelevant to the results.
+// terms are incomplete (k_mm_live<.., true> iterates them).  Order inside the lists is irrelevant to the results.
 __global__ void k_build_rows(const uint8_t* __restrict__ live, const int32_t* __restrict__ cache_len, int n_rows,
                              int n_checks, int32_t* __restrict__ dead_rows, int32_t* __restrict__ live_rows,
                              int32_t* __restrict__ counts /* [0]=dead, [1]=live */) {
@@ -401,7 +402,13 @@ __device__ __forceinline__ void mm_iterate(float (&beta)[E], const RowY<E>& yv, 
     __builtin_amdgcn_wave_barrier();
 }
 
-constexpr int kMaxCycle = 64;  // longest limit cycle looked for on dead rows (periods up to 20 seen at K=1000)
+#ifndef TCLIP_PROBE_CHUNKS
+#define TCLIP_PROBE_CHUNKS 2        // the limit-cycle probe runs after each of the first this-many chunks
+#endif
+#ifndef TCLIP_MAX_CYCLE
+#define TCLIP_MAX_CYCLE 64
+#endif
+constexpr int kMaxCycle = TCLIP_MAX_CYCLE;  // longest limit cycle looked for on dead rows (periods up to 20 seen at K=1000)
 
 #ifndef TCLIP_MM_WAVES_LARGE
 #define TCLIP_MM_WAVES_LARGE 3     // waves per SIMD requested for long rows (E > 8)
@@ -409,8 +416,15 @@ constexpr int kMaxCycle = 64;  // longest limit cycle looked for on dead rows (p
 #ifndef TCLIP_MM_WAVES_SMALL
 #define TCLIP_MM_WAVES_SMALL 4     // waves per SIMD requested for short rows (E <= 8)
 #endif
+// Limit-cycle probe for the dead rows that have just run chunk 0 (k_mm_live<.., true> left b_51 in
+// `beta_dead` and the first stop-test pair in the cache).
+// Dead rows (y = -10 everywhere) contract within ~10-30 iterations onto a short limit cycle of the
+// fp32 map (periods 1..20 observed).  Once b_{l+p} == b_l bit for bit, the trajectory is periodic
+// for ever, so every later checkpoint's (||b'-b||^2, ||b||^2) is one of the p pairs measured
+// here: the remaining ~900 iterations of this row need not be executed.  No cycle within
+// kMaxCycle steps: nothing is assumed, the row keeps iterating chunk by chunk.
 template <int E>
-__global__ __launch_bounds__(256, (E > 8 ? TCLIP_MM_WAVES_LARGE : TCLIP_MM_WAVES_SMALL)) void k_mm_chunk(MMArgs a) {
+__global__ __launch_bounds__(256, (E > 8 ? TCLIP_MM_WAVES_LARGE : TCLIP_MM_WAVES_SMALL)) void k_mm_probe(MMArgs a) {
     __shared__ LogTabEntry tab[16];
     __shared__ double cyc[8][kMaxCycle][2];
     __shared__ float lg_queue[4][64 * E];             // per wave: arguments / results of the large-x lgamma
@@ -423,80 +437,41 @@ __global__ __launch_bounds__(256, (E > 8 ? TCLIP_MM_WAVES_LARGE : TCLIP_MM_WAVES
     const int K = a.K;
     for (int i = blockIdx.x * groups_per_block + group; i < n; i += gridDim.x * groups_per_block) {
         const int row = a.rows[i];
-        if (a.stop[row / a.rows_per_batch]) continue;
-        const bool alive = a.live[row];
-        const float* src = a.alpha;
-        float* dst = a.alpha;
-        if (!alive) {
-            if (!a.has_check || a.cache_len[row] != a.chunk) continue;
-            src = a.chunk == 0 ? a.alpha : a.beta_dead;
-            dst = a.beta_dead;
-        }
+        if (a.stop[row / a.rows_per_batch] || a.cache_len[row] != a.chunk + 1) continue;
+        const float* ref = a.beta_dead + (size_t)row * K;          // b_{l1+1}
         float beta[E];
         RowY<E> yv;
-        yv.load(alive ? a.y + (size_t)row * K : nullptr, lane, K);
+        yv.load(nullptr, lane, K);
 #pragma unroll
         for (int e = 0; e < E; e++) {
             const int d = e * kGroup + lane;
-            beta[e] = d < K ? src[(size_t)row * K + d] : 0.0f;
+            beta[e] = d < K ? ref[d] : 0.0f;
         }
-        double num = 0.0, den = 0.0;
-        for (int l = a.l0; l <= a.l1; l++) mm_iterate<E>(beta, yv, K, lane, tab, queue, a.has_check && l == a.l1, num, den);
+        int period = 0;
+        for (int j = 0; j < kMaxCycle && period == 0; j++) {
+            double pn = 0.0, pd = 0.0;
+            mm_iterate<E>(beta, yv, K, lane, tab, queue, true, pn, pd);
+            pn = group_sum_f64(pn);
+            pd = group_sum_f64(pd);
+            if (lane == 0) { cyc[group][j][0] = pn; cyc[group][j][1] = pd; }
+            bool same = true;
 #pragma unroll
-        for (int e = 0; e < E; e++) {
-            const int d = e * kGroup + lane;
-            if (d < K) dst[(size_t)row * K + d] = beta[e];
+            for (int e = 0; e < E; e++) {
+                const int d = e * kGroup + lane;
+                if (d < K) same = same && (beta[e] == ref[d]);
+            }
+            const unsigned long long bal = __ballot(same);
+            const unsigned int mine = (unsigned int)(bal >> ((threadIdx.x & 32) ? 32 : 0));
+            if (mine == 0xffffffffu) period = j + 1;
         }
-        if (a.work_counter && lane == 0)
-            atomicAdd(a.work_counter, (unsigned long long)K * (unsigned long long)(a.l1 - a.l0 + 1));
-        if (a.has_check) {
-            num = group_sum_f64(num);
-            den = group_sum_f64(den);
-            if (lane == 0) {
-                if (alive) {
-                    a.rowpart[2 * (size_t)row] = num;
-                    a.rowpart[2 * (size_t)row + 1] = den;
-                } else {
-                    double* c = a.cache + ((size_t)row * a.n_checks + a.chunk) * 2;
-                    c[0] = num;
-                    c[1] = den;
-                    a.cache_len[row] = a.chunk + 1;
-                }
+        if (period && lane == 0) {
+            for (int m = a.chunk + 1; m < a.n_checks; m++) {         // the checkpoints still ahead
+                const int j = (50 * (m + 1) - (a.l1 + 1)) % period;
+                double* c = a.cache + ((size_t)row * a.n_checks + m) * 2;
+                c[0] = cyc[group][j][0];
+                c[1] = cyc[group][j][1];
             }
-        }
-        // Dead rows (y = -10 everywhere) contract within ~10-30 iterations onto a short limit cycle
-        // of the fp32 map (periods 1..20 observed).  Once b_{l+p} == b_l bit for bit, the trajectory
-        // is periodic for ever, so every later checkpoint's (||b'-b||^2, ||b||^2) is one of the p
-        // pairs measured here: the remaining ~900 iterations of this row need not be executed.
-        // No cycle within kMaxCycle steps: nothing is assumed, the row keeps iterating normally.
-        if (!alive && a.chunk == 0 && a.has_check && a.n_checks > 1) {
-            int period = 0;
-            for (int j = 0; j < kMaxCycle && period == 0; j++) {
-                double pn = 0.0, pd = 0.0;
-                mm_iterate<E>(beta, yv, K, lane, tab, queue, true, pn, pd);
-                pn = group_sum_f64(pn);
-                pd = group_sum_f64(pd);
-                if (lane == 0) { cyc[group][j][0] = pn; cyc[group][j][1] = pd; }
-                bool same = true;
-#pragma unroll
-                for (int e = 0; e < E; e++) {
-                    const int d = e * kGroup + lane;
-                    if (d < K) same = same && (beta[e] == dst[(size_t)row * K + d]);   // dst holds b_{l1+1}
-                }
-                const unsigned long long bal = __ballot(same);
-                const unsigned int mine = (unsigned int)(bal >> ((threadIdx.x & 32) ? 32 : 0));
-                if (mine == 0xffffffffu) period = j + 1;
-            }
-            if (a.work_counter && lane == 0) atomicAdd(a.work_counter, (unsigned long long)K * kMaxCycle);
-            if (period && lane == 0) {
-                for (int m = 1; m < a.n_checks; m++) {
-                    const int j = (50 * (m + 1) - (a.l1 + 1)) % period;
-                    double* c = a.cache + ((size_t)row * a.n_checks + m) * 2;
-                    c[0] = cyc[group][j][0];
-                    c[1] = cyc[group][j][1];
-                }
-                a.cache_len[row] = a.n_checks;
-            }
+            a.cache_len[row] = a.n_checks;
         }
     }
 }
@@ -594,7 +569,9 @@ __device__ __forceinline__ void mm_iterate_block(float (&beta)[E], const RowY<E>
 #ifndef TCLIP_MM_BLOCK_WAVES
 #define TCLIP_MM_BLOCK_WAVES 4        // waves (= pairs of rows) per block of k_mm_live for E <= 8
 #endif
-template <int E, int W>
+// kDead: the listed rows are dead rows whose cache ends at this chunk: y = -10, the iterate lives in
+// `beta_dead` (their alpha keeps its value, em_dirichlet.py:224-226) and the stop-test pair goes to the cache.
+template <int E, int W, bool kDead>
 __global__ __launch_bounds__(64 * W, (E > 8 ? TCLIP_MM_WAVES_LARGE : TCLIP_MM_WAVES_SMALL)) void k_mm_live(MMArgs a) {
     __shared__ LogTabEntry tab[16];
     __shared__ float queue[64 * W * E];
@@ -610,15 +587,17 @@ __global__ __launch_bounds__(64 * W, (E > 8 ? TCLIP_MM_WAVES_LARGE : TCLIP_MM_WA
     for (int first = blockIdx.x * kRows; first < n; first += gridDim.x * kRows) {   // block-uniform trip count
         const int i = first + group;
         const int row = i < n ? a.rows[i] : 0;
-        const bool active = i < n && !a.stop[row / a.rows_per_batch];
+        const bool active = i < n && !a.stop[row / a.rows_per_batch] && (!kDead || a.cache_len[row] == a.chunk);
         if (!__syncthreads_or(active)) continue;                 // e.g. every batch of these rows has stopped
+        const float* src = (kDead && a.chunk > 0) ? a.beta_dead : a.alpha;
+        float* dst = kDead ? a.beta_dead : a.alpha;
         float beta[E];
         RowY<E> yv;
-        yv.load(a.y + (size_t)row * K, lane, K);
+        yv.load(kDead ? nullptr : a.y + (size_t)row * K, lane, K);
 #pragma unroll
         for (int e = 0; e < E; e++) {
             const int d = e * kGroup + lane;
-            beta[e] = (active && d < K) ? a.alpha[(size_t)row * K + d] : 0.0f;
+            beta[e] = (active && d < K) ? src[(size_t)row * K + d] : 0.0f;
         }
         double num = 0.0, den = 0.0;
         for (int l = a.l0; l <= a.l1; l++)
@@ -627,7 +606,7 @@ __global__ __launch_bounds__(64 * W, (E > 8 ? TCLIP_MM_WAVES_LARGE : TCLIP_MM_WA
 #pragma unroll
         for (int e = 0; e < E; e++) {
             const int d = e * kGroup + lane;
-            if (d < K) a.alpha[(size_t)row * K + d] = beta[e];
+            if (d < K) dst[(size_t)row * K + d] = beta[e];
         }
         if (a.work_counter && lane == 0)
             atomicAdd(a.work_counter, (unsigned long long)K * (unsigned long long)(a.l1 - a.l0 + 1));
@@ -635,8 +614,10 @@ __global__ __launch_bounds__(64 * W, (E > 8 ? TCLIP_MM_WAVES_LARGE : TCLIP_MM_WA
             num = group_sum_f64(num);
             den = group_sum_f64(den);
             if (lane == 0) {
-                a.rowpart[2 * (size_t)row] = num;
-                a.rowpart[2 * (size_t)row + 1] = den;
+                double* out = kDead ? a.cache + ((size_t)row * a.n_checks + a.chunk) * 2 : a.rowpart + 2 * (size_t)row;
+                out[0] = num;
+                out[1] = den;
+                if (kDead) a.cache_len[row] = a.chunk + 1;
             }
         }
     }
@@ -1121,6 +1102,7 @@ struct Profile {
     unsigned long long* counter = nullptr;
 };
 thread_local Profile g_prof;
+static int g_probe_chunks = TCLIP_PROBE_CHUNKS;     // tclip_debug_set_probe_chunks
 
 static hipEvent_t prof_event() {
     if (g_prof.used == g_prof.ev.size()) {
@@ -1200,15 +1182,23 @@ static void dispatch_E(int K, Args... args) {
     else Launcher<32>::run(args...);
 }
 
-template <int E> struct LaunchMM {
-    static void run(int grid, hipStream_t st, MMArgs a) { hipLaunchKernelGGL(k_mm_chunk<E>, dim3(grid), dim3(256), 0, st, a); }
+template <int E> struct LaunchMMProbe {
+    static void run(int grid, hipStream_t st, MMArgs a) { hipLaunchKernelGGL(k_mm_probe<E>, dim3(grid), dim3(256), 0, st, a); }
 };
 template <int E> struct LaunchMMLive {
     static constexpr int kWaves = E > 8 ? 4 : TCLIP_MM_BLOCK_WAVES;
     static void run(int rows, hipStream_t st, MMArgs a) {
         int grid = (rows + 2 * kWaves - 1) / (2 * kWaves);
         if (grid > 256 * 16) grid = 256 * 16;
-        hipLaunchKernelGGL((k_mm_live<E, kWaves>), dim3(grid), dim3(64 * kWaves), 0, st, a);
+        hipLaunchKernelGGL((k_mm_live<E, kWaves, false>), dim3(grid), dim3(64 * kWaves), 0, st, a);
+    }
+};
+template <int E> struct LaunchMMDead {
+    static constexpr int kWaves = LaunchMMLive<E>::kWaves;
+    static void run(int rows, hipStream_t st, MMArgs a) {
+        int grid = (rows + 2 * kWaves - 1) / (2 * kWaves);
+        if (grid > 256 * 16) grid = 256 * 16;
+        hipLaunchKernelGGL((k_mm_live<E, kWaves, true>), dim3(grid), dim3(64 * kWaves), 0, st, a);
     }
 };
 template <int E> struct LaunchRowConsts {
@@ -1333,7 +1323,10 @@ static int enqueue_batches(const tclip_problem& p, const float* x_q, const float
             if (e0 && e1) TCLIP_HIP(hipEventRecord(e1, st));    // the instrumentation covers k_mm_live only
             if (zs && a.has_check) {          // dead rows only matter through their stop-test terms
                 a.rows = mm_rows; a.n_rows = counts; a.work_counter = nullptr;
-                dispatch_E<LaunchMM>(K, grid, st, a);
+                dispatch_E<LaunchMMDead>(K, TK, st, a);
+                // the probe needs the row to be ON its cycle already; rows that were still approaching
+                // it after chunk 0 get a few more chances before they are left to iterate every chunk
+                if (c < g_probe_chunks && c + 1 < a.n_checks) dispatch_E<LaunchMMProbe>(K, grid, st, a);
             }
             hipLaunchKernelGGL(k_mm_decide, dim3(B), dim3(1024), 0, st, (const double*)rowpart, (const double*)cache,
                                (const uint8_t*)live, N * K, a.n_checks, c, a.has_check, a.l1, c == n_chunks - 1 ? 1 : 0,
@@ -1696,6 +1689,11 @@ int tclip_probability_features(const float* visual, const float* text, int64_t n
     hipLaunchKernelGGL(k_probability_features, dim3((unsigned)n_rows), dim3(256), lds, (hipStream_t)stream, visual, text,
                        dim, n_class, temperature, out);
     TCLIP_HIP(hipGetLastError());
+    return TCLIP_OK;
+}
+
+int tclip_debug_set_probe_chunks(int32_t chunks) {
+    g_probe_chunks = chunks < 0 ? TCLIP_PROBE_CHUNKS : chunks;
     return TCLIP_OK;
 }
 

@@ -227,6 +227,12 @@ def gather_rows(table, idx):
     return out
 
 
+def debug_set_probe_chunks(chunks=-1):
+    """Test hook: run the dead rows' limit-cycle probe after the first `chunks` chunks (0 = never,
+    negative = default).  Results do not depend on it."""
+    _capi.check(_capi.lib().tclip_debug_set_probe_chunks(int(chunks)), "tclip_debug_set_probe_chunks")
+
+
 def profile_enable(on=True):
     _capi.check(_capi.lib().tclip_profile_enable(int(bool(on))), "tclip_profile_enable")
 
