@@ -12,10 +12,8 @@ _lib = None
 def lib():
     global _lib
     if _lib is None:
-        path = os.path.join(HERE, "_tclip_oracle.so")
-        if not os.path.exists(path):
-            from oracle import build as _b
-            _b.build()
+        from oracle import build as _b
+        path = _b.build()[0]                       # rebuilt whenever the source or the math header changed
         l = ctypes.CDLL(path)
         for f in ("tclip_oracle_sum_inner", "tclip_oracle_sum_outer", "tclip_oracle_sum_reduce_all"):
             getattr(l, f).restype = ctypes.c_float

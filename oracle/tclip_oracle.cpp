@@ -77,10 +77,15 @@ inline float sum_ilp4(long n, F get) {
 // torch sum over a strided dimension, for output column `col` of `ncols` contiguous columns
 // (vectorized_outer_sum): the leading multiple of 4 vectors (32 floats; sum_stub is registered
 // without the AVX-512 variant, so vectors are 8 floats wide even on AVX-512 hosts) goes
-// through the plain cascade, the remaining columns through the ILP-4 row sum.
+// through the plain cascade, the remaining columns through the ILP-4 row sum.  With fewer than 8
+// columns ATen takes scalar_outer_sum instead: groups of 4 columns through the cascade, the
+// 1-3 left over through the ILP-4 row sum.
+inline bool outer_column_is_cascade(long col, long ncols) {
+    return ncols >= 8 ? col < (ncols / 32) * 32 : col < (ncols / 4) * 4;
+}
 template <typename F>
 inline float sum_outer(long n, long col, long ncols, F get) {
-    return col < (ncols / 32) * 32 ? sum_cascade(n, get) : sum_ilp4(n, get);
+    return outer_column_is_cascade(col, ncols) ? sum_cascade(n, get) : sum_ilp4(n, get);
 }
 
 // torch sum over the contiguous last dimension (vectorized_inner_sum with 8-float vectors and

@@ -62,7 +62,7 @@ def load_reference_classes():
 
 # PADDLE's lambd is a tunable float (paddle.yaml: 0.0); the fixtures also use a value that makes the
 # class-proportion term matter
-PADDLE_LAMBD = {"fs_paddle_K10_N4_s4": 0.0, "fs_paddle_K37_N3_s2": 20.0, "fs_paddle_K100_N3_s1": 5.0,
+PADDLE_LAMBD = {"fs_paddle_K5_N3_s2": 2.5, "fs_paddle_K10_N4_s4": 0.0, "fs_paddle_K37_N3_s2": 20.0, "fs_paddle_K100_N3_s1": 5.0,
                 "fs_paddle_K397_N1_s1": 10.0}
 
 
@@ -86,6 +86,17 @@ SMALL = {
     "zs_hkm_K37_N6": ("zs_hkm", 37, 6, 20, 0, 2021, True),
     "zs_hkm_K100_N4": ("zs_hkm", 100, 4, 20, 0, 2022, True),
     "zs_hkm_K397_N2": ("zs_hkm", 397, 2, 20, 0, 2023, True),
+    # fewer than 8 classes: ATen's scalar reduction paths (scalar_inner_sum, scalar_outer_sum)
+    "zs_soft_K7_N4": ("zs_soft", 7, 4, 20, 0, 2030, True),
+    "zs_soft_K2_N4": ("zs_soft", 2, 4, 20, 0, 2031, True),
+    "zs_hard_K5_N4": ("zs_hard", 5, 4, 10, 0, 2032, True),
+    "fs_soft_K6_N3_s2": ("fs_soft", 6, 3, 20, 2, 2033, True),
+    "zs_skm_K7_N4": ("zs_skm", 7, 4, 20, 0, 2034, True),
+    "zs_skm_K2_N4": ("zs_skm", 2, 4, 20, 0, 2035, True),
+    "zs_hkm_K2_N4": ("zs_hkm", 2, 4, 20, 0, 2036, True),
+    "zs_hkm_K5_N4": ("zs_hkm", 5, 4, 20, 0, 2037, True),
+    "zs_emg_K7_N4": ("zs_emg", 7, 4, 20, 0, 2038, True),
+    "fs_paddle_K5_N3_s2": ("fs_paddle", 5, 3, 20, 2, 2039, True),
     "zs_emg_K10_N4": ("zs_emg", 10, 4, 20, 0, 2020, True),
     "zs_emg_K37_N6": ("zs_emg", 37, 6, 20, 0, 2021, True),
     "zs_emg_K100_N4": ("zs_emg", 100, 4, 20, 0, 2022, True),

@@ -11,7 +11,7 @@ import pytest
 from conftest import GOLDEN, golden_names
 from oracle import c_oracle
 
-FAST = [n for n in golden_names() if ("K10_" in n or "K37_" in n) and not n.startswith("eval_")]
+FAST = [n for n in golden_names() if any(f"K{k}_" in n for k in (2, 5, 6, 7, 10, 37)) and not n.startswith("eval_")]
 
 
 def _borderline(g):

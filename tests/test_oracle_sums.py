@@ -37,7 +37,8 @@ def test_inner_and_outer_sum_order(n):
         assert lib.tclip_oracle_sum_outer(_p(x), ctypes.c_long(n), ctypes.c_long(t), ctypes.c_long(T)) == outer[t]
 
 
-@pytest.mark.parametrize("shape", [(3, 75, 10), (2, 75, 37), (2, 75, 100), (2, 148, 37)])
+@pytest.mark.parametrize("shape", [(3, 75, 10), (2, 75, 37), (2, 75, 100), (2, 148, 37), (4, 75, 2), (4, 75, 3), (4, 75, 4),
+                                   (4, 75, 5), (4, 75, 6), (4, 75, 7), (4, 75, 8), (4, 75, 9), (3, 20, 5), (3, 75, 21)])
 def test_mstep_statistics_order(shape):
     """(u.unsqueeze(-1) * logz.unsqueeze(2)).sum(1) and u.sum(1), the reference's M-step sums."""
     lib = c_oracle.lib()

@@ -9,7 +9,8 @@
 //     8 lanes;
 //   * sums over the query dimension (u.sum(1), the u^T log z statistics): vectorized_outer_sum -
 //     per output column a 16-element cascade, except the last (#columns mod 32) columns, which go
-//     through the 4-way interleaved row sum;
+//     through the 4-way interleaved row sum (fewer than 8 columns: scalar_outer_sum, the same in
+//     groups of 4 columns);
 //   * softmax denominators: vec::reduce_all on 16-float vectors + 8/4/2/1 butterfly.
 // oracle/tclip_oracle.cpp restates the same orders on the CPU and tests/test_oracle_sums.py pins
 // them bit-for-bit against torch.  Element d of a K-vector lives in register e = d / 32 of lane
@@ -127,10 +128,15 @@ __device__ __forceinline__ float dsum_ilp4(int n, F get) {
     return p0;
 }
 
-// torch's sum over a strided dimension for output column `col` of `ncols` contiguous columns.
+// torch's sum over a strided dimension for output column `col` of `ncols` contiguous columns:
+// vectorized_outer_sum sends the leading multiple of 32 columns through the cascade and the rest
+// through the 4-way row sum; with fewer than 8 columns scalar_outer_sum does the same in groups of 4.
+__device__ __forceinline__ bool outer_column_is_cascade(long col, long ncols) {
+    return ncols >= 8 ? col < (ncols / 32) * 32 : col < (ncols / 4) * 4;
+}
 template <typename F>
 __device__ __forceinline__ float dsum_outer(int n, long col, long ncols, F get) {
-    return col < (ncols / 32) * 32 ? dsum_cascade(n, get) : dsum_ilp4(n, get);
+    return outer_column_is_cascade(col, ncols) ? dsum_cascade(n, get) : dsum_ilp4(n, get);
 }
 
 // torch's contiguous last-dim sum evaluated serially by one thread (small n only).

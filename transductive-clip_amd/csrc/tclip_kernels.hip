@@ -128,7 +128,7 @@ __global__ void k_support_stats(const float* __restrict__ xs, const int64_t* __r
     for (int d = threadIdx.x; d < K; d += blockDim.x) {
         const long col = (long)k * K + d;
         float r;
-        if (col < (ncols / 32) * 32) {
+        if (outer_column_is_cascade(col, ncols)) {
             SparseCascade c(S);
             for (int i = 0; i < nm; i++) {
                 const float x = xt[(size_t)members[i] * K + d];
