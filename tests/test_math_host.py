@@ -78,9 +78,17 @@ def test_sqrt_bit_exact_vs_torch(mc):
     assert 0.003 < (ref != np.sqrt(x.numpy())).mean() < 0.012     # ... and torch's is indeed not IEEE
 
 
-def test_log_close_to_torch(mc):
-    x = _loguniform(1e-12, 1.0, 1 << 20, 5)
-    assert (_call(mc, "mc_log", x.numpy()) != torch.log(x).numpy()).mean() <= 2e-3
+@pytest.mark.skipif(torch.backends.cpu.get_cpu_capability() != "AVX512",
+                    reason="the restated kernel is MKL's AVX-512 vsLn; other hosts dispatch another one")
+def test_log_bit_exact_vs_torch(mc):
+    """MKL vsLn (HA, AVX-512 kernel) restated from its disassembly: every float of [0.5, 2) - where
+    MKL is one ulp off the correctly rounded value on 1e-3 of arguments - and 4e6 log-uniform
+    arguments over the rest of the restated range."""
+    x = np.arange(0x3f000000, 0x40000000, dtype=np.uint32).view(np.float32)
+    assert np.array_equal(_call(mc, "mc_log", x).view(np.uint32), torch.log(torch.from_numpy(x)).numpy().view(np.uint32))
+    for lo, hi, seed in ((1e-30, 1e-15, 5), (1e-15, 0.5, 6), (2.0, 1e30, 7)):
+        y = _loguniform(lo, hi, 1 << 21, seed)
+        assert np.array_equal(_call(mc, "mc_log", y.numpy()).view(np.uint32), torch.log(y).numpy().view(np.uint32))
 
 
 def test_exp_matches_torch_softmax_exp(mc):

@@ -1,7 +1,6 @@
 """CPU: the C++ oracle (oracle/tclip_oracle.cpp) against the golden vectors the reference
 produced.  Every special function and reduction order of torch CPU is restated bit for bit
-(only torch.log = MKL vsLn is replaced by the correctly rounded value, 1 ulp apart on ~1e-4 of
-arguments), and on every fixture the oracle reproduces the reference's alpha, u and v EXACTLY,
+(torch.log = MKL vsLn included), and on every fixture the oracle reproduces the reference's alpha, u and v EXACTLY,
 with identical MM iteration counts and argmax traces."""
 import os
 

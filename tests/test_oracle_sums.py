@@ -23,7 +23,8 @@ def _avx_like():
 pytestmark = pytest.mark.skipif(not _avx_like(), reason="reduction orders pinned for the AVX2/AVX-512 ATen kernels")
 
 
-@pytest.mark.parametrize("n", [3, 7, 8, 10, 15, 16, 37, 75, 100, 397, 1000, 1024, 4000])
+@pytest.mark.parametrize("n", [1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 15, 16, 17, 31, 32, 33, 37, 63, 64, 65, 75, 100, 127, 128, 129, 255,
+                               256, 257, 397, 511, 512, 513, 1000, 1024, 4000])
 def test_inner_and_outer_sum_order(n):
     lib = c_oracle.lib()
     torch.manual_seed(n)
