@@ -1,4 +1,6 @@
-"""Randomised parity sweep on the GPU box: python3 scripts/gpu_fuzz.py [n_cases] [seed]
+"""Randomised parity sweep on the GPU box: python3 scripts/gpu_fuzz.py [n_cases] [seed] [full]
+("full": the reference's whole 20 x 1000 / 10 x 1000 schedule on small problems, which exercises the
+stop test at every checkpoint, dead rows, their cache and the limit-cycle shortcut)
 Random (K, Q, tasks, batches, hard, few-shot, schedule) against the C++ oracle, bit for bit, each
 case run twice (run-to-run determinism)."""
 import os, random, sys, time
@@ -11,6 +13,7 @@ from tclip_amd import engine, synth
 
 n_cases = int(sys.argv[1]) if len(sys.argv) > 1 else 40
 rng = random.Random(int(sys.argv[2]) if len(sys.argv) > 2 else 1)
+full = len(sys.argv) > 3 and sys.argv[3] == "full"
 bad = 0
 t0 = time.time()
 for case in range(n_cases):
@@ -19,9 +22,11 @@ for case in range(n_cases):
     few = rng.random() < 0.3
     hard = rng.random() < 0.4
     B = rng.randint(1, 4)
-    budget = 1.5e8 / (K * K)                                   # element-updates the CPU oracle can afford
-    iter_mm = rng.choice([30, 51, 60, 101, 120, 151, 230])
-    iters = rng.randint(2, 4)
+    if full:
+        K = rng.choice([2, 3, 5, 7, 8, 9, 10, 12, 16, 20, 33, 40])
+    budget = (4e8 if full else 1.5e8) / (K * K)                # element-updates the CPU oracle can afford
+    iter_mm = 1000 if full else rng.choice([30, 51, 60, 101, 120, 151, 230])
+    iters = (10 if hard else 20) if full else rng.randint(2, 4)
     N = max(1, min(6, int(budget / (iter_mm * iters * B))))
     lambd = max(1, int(K / 5)) * Q
     x_q, _ = synth.make_query_tasks(B * N, K, seed=1000 + case, n_query=Q, k_eff=(min(3, K) if few else None))
