@@ -18,7 +18,7 @@ bad = 0
 t0 = time.time()
 for case in range(n_cases):
     K = rng.choice([2, 3, 5, 8, 9, 17, 31, 32, 33, 40, 64, 65, 96, 100, 101, 129, 160, 200, 257, 300])
-    Q = rng.choice([20, 75])
+    Q = rng.choice([1, 2, 5, 17, 20, 64, 75, 130])
     few = rng.random() < 0.3
     hard = rng.random() < 0.4
     B = rng.randint(1, 4)
