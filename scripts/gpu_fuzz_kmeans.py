@@ -1,7 +1,9 @@
 """Randomised parity sweep of the k-means family on the GPU box: python3 scripts/gpu_fuzz_kmeans.py [n_cases] [seed]
 SOFT_KMEANS and HARD_KMEANS have no logarithm in their loop and must equal the torch-eager oracle
-bit for bit on any host; EM_GAUSSIAN and PADDLE go through torch.log on the host side of the
-comparison, so they are compared to 1e-5 (see tests/test_paddle.py)."""
+bit for bit when the host's torch runs the AVX-512 kernels with at most 8 threads.  EM_GAUSSIAN and
+PADDLE go through torch.log = MKL vsLn on the host side, whose kernel choice differs between hosts
+(the GPU pool's host does not reproduce the fixture host's logs), so they are compared to 1e-4 here;
+their bit-exactness is pinned by the fixtures the reference produced on the fixture host."""
 import os, random, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "transductive-clip_amd"))
@@ -9,10 +11,12 @@ import torch
 from oracle import ref_torch
 from tclip_amd import engine, synth
 
+torch.set_num_threads(min(8, torch.get_num_threads()))      # the reference changes with 16+ threads (scripts/host_threads_check.py)
 # torch on this host is the comparison target: its reduction orders are the AVX-512 ones only there
 exact_host = torch.backends.cpu.get_cpu_capability() == "AVX512"
 print("host torch capability:", torch.backends.cpu.get_cpu_capability(), "-> exact comparison" if exact_host else "-> 1e-5 comparison")
-same = torch.equal if exact_host else (lambda a, b: torch.allclose(a, b, rtol=1e-5, atol=1e-8))
+close = lambda a, b: torch.allclose(a, b, rtol=1e-4, atol=1e-7, equal_nan=True)
+same = torch.equal if exact_host else close
 n_cases = int(sys.argv[1]) if len(sys.argv) > 1 else 40
 rng = random.Random(int(sys.argv[2]) if len(sys.argv) > 2 else 1)
 bad = 0
@@ -29,15 +33,15 @@ for case in range(n_cases):
     ok_hkm = same(u.cpu(), t["u"]) and same(w.cpu(), t["w"]) and torch.equal(p.cpu().long(), t["labels"][-1])
     u, v, w, p = engine.run_em_gaussian(xc, iters=iters, temperature=30, lambd=int(K / 5) * 75)
     t = ref_torch.run_em_gaussian(x_q, n_class=K, iters=iters, temperature=30, lambd=int(K / 5) * 75)
-    ok_emg = torch.allclose(u.cpu(), t["u"], rtol=1e-4, atol=1e-7) and torch.allclose(w.cpu(), t["w"], rtol=1e-4, atol=1e-7)
+    ok_emg = close(u.cpu(), t["u"]) and close(w.cpu(), t["w"])
     shots = rng.randint(1, 3)
     x_s, y_s = synth.make_support(N, K, shots, seed=4000 + case)
     lam = rng.choice([0.0, 3.0, 12.5])
     u, v, w, p = engine.run_paddle(xc, x_s.cuda(), y_s.squeeze(2).cuda(), iters=iters, lambd=lam)
     t = ref_torch.run_paddle(x_q, x_s, y_s, n_class=K, iters=iters, lambd=lam)
-    ok_pad = torch.allclose(u.cpu(), t["u"], rtol=1e-4, atol=1e-7, equal_nan=True) and torch.allclose(w.cpu(), t["w"], rtol=1e-4, atol=1e-7, equal_nan=True)
+    ok_pad = close(u.cpu(), t["u"]) and close(w.cpu(), t["w"])
     ok = ok_skm and ok_hkm and ok_emg and ok_pad
     bad += not ok
     print(f"case {case}: K={K} N={N} iters={iters} shots={shots} lambd={lam} skm={ok_skm} hkm={ok_hkm} emg={ok_emg} paddle={ok_pad} -> {'ok' if ok else 'MISMATCH'}", flush=True)
-print(f"{n_cases - bad}/{n_cases} cases ok")
+print(f"{n_cases - bad}/{n_cases} cases passed")
 sys.exit(1 if bad else 0)

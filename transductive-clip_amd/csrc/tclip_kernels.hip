@@ -196,8 +196,8 @@ __global__ void k_cluster_sizes(const float* __restrict__ u, int T, int Q, int K
 // prototypes of the accuracy tail (em_dirichlet.py:66-67).
 __global__ void k_mstats(const float* __restrict__ u, const float* __restrict__ f, const float* __restrict__ cs,
                          const uint8_t* __restrict__ live, const float* __restrict__ sup,
-                         const float* __restrict__ cnt, int Q, int K, float* __restrict__ y, int paddle = 0) {
-    const int t = blockIdx.z, k = blockIdx.y;
+                         const float* __restrict__ cnt, int Q, int K, float* __restrict__ y, int paddle, int k_first) {
+    const int t = blockIdx.z, k = blockIdx.y + k_first;
     const int d = blockIdx.x * blockDim.x + threadIdx.x;
     const size_t row = (size_t)t * K + k;
     if (d >= K || !live[row]) return;
@@ -213,6 +213,66 @@ __global__ void k_mstats(const float* __restrict__ u, const float* __restrict__ 
         y[row * K + d] = w * (sup[row * K + d] + s);
     } else {
         y[row * K + d] = s / (c < kEpsF ? kEpsF : c);
+    }
+}
+
+// The same statistics for kMstatsRows consecutive classes per thread, for the rows whose columns all
+// take the cascade order (every row but the last few): the feature block of a task is then read
+// from L2 once per 8 classes instead of once per class, the u values are wave-uniform loads, and
+// each output keeps its own cascade state, so the sums are the ones dsum_cascade builds.
+constexpr int kMstatsRows = 8;
+__global__ __launch_bounds__(64) void k_mstats_rows(const float* __restrict__ u, const float* __restrict__ f,
+                                                    const float* __restrict__ cs, const uint8_t* __restrict__ live,
+                                                    const float* __restrict__ sup, const float* __restrict__ cnt, int Q,
+                                                    int K, float* __restrict__ y, int paddle) {
+    const int t = blockIdx.z, k0 = blockIdx.y * kMstatsRows;
+    const int d = blockIdx.x * blockDim.x + threadIdx.x;
+    if (d >= K) return;
+    const float* ut = u + (size_t)t * Q * K + k0;
+    const float* ft = f + (size_t)t * Q * K + d;
+    const int cl = dev_ceil_log2(Q) / 4;
+    const int level_power = cl > 4 ? cl : 4;
+    const int step = 1 << level_power, mask = step - 1;
+    float a0[kMstatsRows], a1[kMstatsRows], a2[kMstatsRows], a3[kMstatsRows];
+#pragma unroll
+    for (int j = 0; j < kMstatsRows; j++) a0[j] = a1[j] = a2[j] = a3[j] = 0.0f;
+    int i = 0;
+    for (; i + step <= Q;) {
+        for (int jj = 0; jj < step; ++jj, ++i) {
+            const float fv = ft[(size_t)i * K];
+#pragma unroll
+            for (int j = 0; j < kMstatsRows; j++) a0[j] += ut[(size_t)i * K + j] * fv;
+        }
+        const bool l2 = (i & (mask << level_power)) == 0, l3 = l2 && (i & (mask << (2 * level_power))) == 0;
+#pragma unroll
+        for (int j = 0; j < kMstatsRows; j++) {
+            a1[j] += a0[j]; a0[j] = 0.0f;
+            if (l2) { a2[j] += a1[j]; a1[j] = 0.0f; }
+            if (l3) { a3[j] += a2[j]; a2[j] = 0.0f; }
+        }
+    }
+    for (; i < Q; ++i) {
+        const float fv = ft[(size_t)i * K];
+#pragma unroll
+        for (int j = 0; j < kMstatsRows; j++) a0[j] += ut[(size_t)i * K + j] * fv;
+    }
+#pragma unroll
+    for (int j = 0; j < kMstatsRows; j++) {
+        const size_t row = (size_t)t * K + k0 + j;
+        if (!live[row]) continue;
+        float s = a0[j];
+        s += a1[j];
+        s += a2[j];
+        s += a3[j];
+        const float c = cs[row];
+        if (sup && paddle) {
+            y[row * K + d] = (s + sup[row * K + d]) / (c + cnt[row]);
+        } else if (sup) {
+            const float w = 1.0f / (cnt[row] + c);
+            y[row * K + d] = w * (sup[row * K + d] + s);
+        } else {
+            y[row * K + d] = s / (c < kEpsF ? kEpsF : c);
+        }
     }
 }
 
@@ -735,34 +795,51 @@ __global__ __launch_bounds__(256) void k_logits(const float* __restrict__ alpha,
 
 // k-means E-step: logit[t,q,k] = temperature * (pre * sum_d (w[t,k,d] - z[t,q,d])^2), the sum in torch's
 // last-dim order; SOFT_KMEANS (soft_kmeans.py:105-125): pre = -1/2, temperature = T; HARD_KMEANS
-// (hard_kmeans.py:26-35): pre = temperature = 1, i.e. the plain squared distance.  Same structure as k_logits.
-template <int E>
-__global__ __launch_bounds__(256) void k_kmeans_logits(const float* __restrict__ w, const float* __restrict__ z,
-                                                       const int32_t* __restrict__ rows, const int32_t* __restrict__ n_rows,
-                                                       int Q, int K, float pre, float temperature, float* __restrict__ logit0) {
+// (hard_kmeans.py:26-35): pre = temperature = 1, i.e. the plain squared distance.
+// A block handles kRowsPerBlock consecutive classes of one task: a query row is loaded once and used
+// against all of them (the task's feature block would otherwise be re-read from L2 once per class;
+// four classes per block made SOFT_KMEANS at K = 397 2.4x faster).  `need` marks the (task, class)
+// rows to (re)compute.
+template <int E, int kRowsPerBlock>
+__global__ __launch_bounds__(256) void k_kmeans_logits_rows(const float* __restrict__ w, const float* __restrict__ z,
+                                                            const uint8_t* __restrict__ need, int Q, int K, float pre,
+                                                            float temperature, float* __restrict__ logit0) {
     const int lane = threadIdx.x & (kGroup - 1);
     const int group = threadIdx.x / kGroup, groups_per_block = blockDim.x / kGroup;
-    const int n = *n_rows;
-    for (int i = blockIdx.x; i < n; i += gridDim.x) {
-        const int row = rows[i];
-        const int t = row / K, k = row % K;
-        float wv[E];
+    const int t = blockIdx.y, k0 = blockIdx.x * kRowsPerBlock;
+    bool want[kRowsPerBlock];
+    bool any = false;
+    float wv[kRowsPerBlock][E];
+#pragma unroll
+    for (int j = 0; j < kRowsPerBlock; j++) {
+        want[j] = k0 + j < K && need[(size_t)t * K + k0 + j];
+        any = any || want[j];
 #pragma unroll
         for (int e = 0; e < E; e++) {
             const int d = e * kGroup + lane;
-            wv[e] = d < K ? w[(size_t)row * K + d] : 0.0f;
+            wv[j][e] = (want[j] && d < K) ? w[((size_t)t * K + k0 + j) * K + d] : 0.0f;
         }
-        for (int q = group; q < Q; q += groups_per_block) {
-            const float* zq = z + ((size_t)t * Q + q) * K;
+    }
+    if (!any) return;
+    for (int q = group; q < Q; q += groups_per_block) {
+        const float* zq = z + ((size_t)t * Q + q) * K;
+        float zv[E];
+#pragma unroll
+        for (int e = 0; e < E; e++) {
+            const int d = e * kGroup + lane;
+            zv[e] = d < K ? zq[d] : 0.0f;
+        }
+#pragma unroll
+        for (int j = 0; j < kRowsPerBlock; j++) {
+            if (!want[j]) continue;                                  // block-uniform
             float pr[E];
 #pragma unroll
             for (int e = 0; e < E; e++) {
-                const int d = e * kGroup + lane;
-                const float df = d < K ? wv[e] - zq[d] : 0.0f;
+                const float df = e * kGroup + lane < K ? wv[j][e] - zv[e] : 0.0f;
                 pr[e] = df * df;
             }
             const float ssum = group_sum_torch<E>(pr, K, lane);
-            if (lane == 0) logit0[((size_t)t * Q + q) * K + k] = temperature * (pre * ssum);
+            if (lane == 0) logit0[((size_t)t * Q + q) * K + k0 + j] = temperature * (pre * ssum);
         }
     }
 }
@@ -1213,12 +1290,29 @@ template <int E> struct LaunchLogits {
     }
 };
 
-template <int E> struct LaunchKmeansLogits {
-    static void run(int grid, hipStream_t st, const float* w, const float* z, const int32_t* rows, const int32_t* n,
-                    int Q, int K, float pre, float temperature, float* logit0) {
-        hipLaunchKernelGGL(k_kmeans_logits<E>, dim3(grid), dim3(256), 0, st, w, z, rows, n, Q, K, pre, temperature, logit0);
+template <int E> struct LaunchKmeansLogitsRows {
+    static void run(int T, hipStream_t st, const float* w, const float* z, const uint8_t* need, int Q, int K, float pre,
+                    float temperature, float* logit0) {
+        constexpr int kRows = E <= 16 ? 4 : 2;                       // registers: kRows x E for the centroids
+        hipLaunchKernelGGL((k_kmeans_logits_rows<E, kRows>), dim3((K + kRows - 1) / kRows, T), dim3(256), 0, st, w, z, need, Q, K,
+                           pre, temperature, logit0);
     }
 };
+
+// M-step statistics / centroids / prototypes: rows whose K columns all lie in torch's cascade region
+// go through the 8-rows-per-thread kernel, the last few rows through the one-row kernel.
+static void launch_mstats(hipStream_t st, const float* u, const float* f, const float* cs, const uint8_t* live,
+                          const float* sup, const float* cnt, int T, int Q, int K, float* y, int paddle) {
+    const long ncols = (long)K * K;
+    const int full_rows = ncols >= 8 ? (int)(((ncols / 32) * 32) / K) : 0;      // rows 0 .. full_rows-1 are all-cascade
+    const int groups = full_rows / kMstatsRows;
+    if (groups > 0)
+        hipLaunchKernelGGL(k_mstats_rows, dim3((K + 63) / 64, groups, T), dim3(64), 0, st, u, f, cs, live, sup, cnt, Q, K, y, paddle);
+    const int k_first = groups * kMstatsRows;
+    if (k_first < K)
+        hipLaunchKernelGGL(k_mstats, dim3((K + 63) / 64, K - k_first, T), dim3(64), 0, st, u, f, cs, live, sup, cnt, Q, K, y,
+                           paddle, k_first);
+}
 
 static int ew_grid(size_t n) {
     size_t g = (n + 255) / 256;
@@ -1297,8 +1391,7 @@ static int enqueue_batches(const tclip_problem& p, const float* x_q, const float
         // ---- M-step statistics
         hipLaunchKernelGGL(k_cluster_sizes, dim3((TK + 255) / 256), dim3(256), 0, st, (const float*)u, T, Q, K, zs ? 1 : 0,
                            cs, live, v, cache_len);
-        hipLaunchKernelGGL(k_mstats, dim3((K + 63) / 64, K, T), dim3(64), 0, st, (const float*)u, (const float*)logz,
-                           (const float*)cs, (const uint8_t*)live, (const float*)sup, (const float*)cnt, Q, K, y);
+        launch_mstats(st, (const float*)u, (const float*)logz, (const float*)cs, (const uint8_t*)live, (const float*)sup, (const float*)cnt, T, Q, K, y, 0);
         TCLIP_HIP(hipMemsetAsync(counts, 0, 256, st));
         TCLIP_HIP(hipMemsetAsync(stop, 0, (size_t)B * 4, st));
         hipLaunchKernelGGL(k_build_rows, dim3((TK + 255) / 256), dim3(256), 0, st, (const uint8_t*)live,
@@ -1510,30 +1603,22 @@ static int soft_kmeans_core(const tclip_problem& p, const float* x_q, float temp
     uint8_t* live = (uint8_t*)(ws + o_live);
     uint8_t* ones = (uint8_t*)(ws + o_ones);
     float* logit0 = (float*)(ws + o_logit);
-    int32_t* rows = (int32_t*)(ws + o_rows);
-    int32_t* scratch_rows = (int32_t*)(ws + o_scratch);
-    int32_t* counts = (int32_t*)(ws + o_counts);
     hipLaunchKernelGGL(k_copy, dim3(ew_grid(TQK)), dim3(256), 0, st, x_q, u, TQK);          // u = z
     TCLIP_HIP(hipMemsetAsync(ones, 1, (size_t)TK, st));
     if (v) hipLaunchKernelGGL(k_fill, dim3(ew_grid(TK)), dim3(256), 0, st, v, 0.0f, (size_t)TK);
     // w_init: every centroid = u^T z / clamp(sum u)                             (soft_kmeans.py:137-149)
     hipLaunchKernelGGL(k_cluster_sizes, dim3((TK + 255) / 256), dim3(256), 0, st, (const float*)u, T, Q, K, 1, cs, live,
                        (float*)nullptr, (int32_t*)nullptr);
-    hipLaunchKernelGGL(k_mstats, dim3((K + 63) / 64, K, T), dim3(64), 0, st, (const float*)u, x_q, (const float*)cs,
-                       (const uint8_t*)ones, (const float*)nullptr, (const float*)nullptr, Q, K, w);
+    launch_mstats(st, (const float*)u, (const float*)x_q, (const float*)cs, (const uint8_t*)ones, (const float*)nullptr, (const float*)nullptr, T, Q, K, w, 0);
     for (int it = 0; it < p.iters; it++) {
         // w_update: live clusters get the new mean, empty ones keep their centroid   (:151-168)
         // EM_GAUSSIAN: the same pass over u also yields v of the previous iteration's v_update (v stays 0 before the first)
         hipLaunchKernelGGL(k_cluster_sizes, dim3((TK + 255) / 256), dim3(256), 0, st, (const float*)u, T, Q, K, 1, cs,
                            live, it > 0 ? v : (float*)nullptr, (int32_t*)nullptr);
-        hipLaunchKernelGGL(k_mstats, dim3((K + 63) / 64, K, T), dim3(64), 0, st, (const float*)u, x_q, (const float*)cs,
-                           (const uint8_t*)live, (const float*)nullptr, (const float*)nullptr, Q, K, w);
+        launch_mstats(st, (const float*)u, (const float*)x_q, (const float*)cs, (const uint8_t*)live, (const float*)nullptr, (const float*)nullptr, T, Q, K, w, 0);
         // distances only for centroids that moved (all of them in the first iteration)
-        TCLIP_HIP(hipMemsetAsync(counts, 0, 256, st));
-        hipLaunchKernelGGL(k_build_rows, dim3((TK + 255) / 256), dim3(256), 0, st, (const uint8_t*)(it == 0 ? ones : live),
-                           (const int32_t*)nullptr, TK, 0, scratch_rows, rows, counts);
-        dispatch_E<LaunchKmeansLogits>(K, TK > 16384 ? 16384 : TK, st, (const float*)w, x_q, (const int32_t*)rows,
-                                       (const int32_t*)(counts + 1), Q, K, -0.5f, temperature, logit0);
+        dispatch_E<LaunchKmeansLogitsRows>(K, T, st, (const float*)w, x_q, (const uint8_t*)(it == 0 ? ones : live), Q, K, -0.5f,
+                                           temperature, logit0);
         hipLaunchKernelGGL(k_softmax, dim3((T * Q * 16 + 255) / 256), dim3(256), 0, st, (const float*)logit0,
                            (const float*)v, T * Q, Q, K, (float)p.lambd, 0, 0, u, preds);
     }
@@ -1581,25 +1666,17 @@ int tclip_hard_kmeans_run(const tclip_problem* pp, const float* x_q, float* u, f
     uint8_t* live = (uint8_t*)(ws + o_live);
     uint8_t* ones = (uint8_t*)(ws + o_ones);
     float* logit0 = (float*)(ws + o_logit);
-    int32_t* rows = (int32_t*)(ws + o_rows);
-    int32_t* scratch_rows = (int32_t*)(ws + o_scratch);
-    int32_t* counts = (int32_t*)(ws + o_counts);
     float* change = (float*)(ws + o_change);
     hipLaunchKernelGGL(k_copy, dim3(ew_grid(TQK)), dim3(256), 0, st, x_q, u, TQK);          // u = z
-    TCLIP_HIP(hipMemsetAsync(ones, 1, (size_t)TK, st));
-    TCLIP_HIP(hipMemsetAsync(counts, 0, 256, st));
-    hipLaunchKernelGGL(k_build_rows, dim3((TK + 255) / 256), dim3(256), 0, st, (const uint8_t*)ones, (const int32_t*)nullptr,
-                       TK, 0, scratch_rows, rows, counts);                                  // every centroid, every iteration
+    TCLIP_HIP(hipMemsetAsync(ones, 1, (size_t)TK, st));                                     // every centroid moves every iteration
     for (int it = 0; it < p.iters; it++) {
         // w_update: mean of the members, zero for empty clusters                            (hard_kmeans.py:138-152)
         hipLaunchKernelGGL(k_cluster_sizes, dim3((TK + 255) / 256), dim3(256), 0, st, (const float*)u, T, Q, K, 1, cs,
                            live, (float*)nullptr, (int32_t*)nullptr);
-        hipLaunchKernelGGL(k_mstats, dim3((K + 63) / 64, K, T), dim3(64), 0, st, (const float*)u, x_q, (const float*)cs,
-                           (const uint8_t*)live, (const float*)nullptr, (const float*)nullptr, Q, K, w);
+        launch_mstats(st, (const float*)u, (const float*)x_q, (const float*)cs, (const uint8_t*)live, (const float*)nullptr, (const float*)nullptr, T, Q, K, w, 0);
         hipLaunchKernelGGL(k_zero_dead_rows, dim3(ew_grid((size_t)TK * K)), dim3(256), 0, st, (const uint8_t*)live, TK, K, w);
         // u_update + hard assignment: softmax of the squared distances, first minimum    (:128-136, :193-195)
-        dispatch_E<LaunchKmeansLogits>(K, TK > 16384 ? 16384 : TK, st, (const float*)w, x_q, (const int32_t*)rows,
-                                       (const int32_t*)(counts + 1), Q, K, 1.0f, 1.0f, logit0);
+        dispatch_E<LaunchKmeansLogitsRows>(K, T, st, (const float*)w, x_q, (const uint8_t*)ones, Q, K, 1.0f, 1.0f, logit0);
         hipLaunchKernelGGL(k_softmax, dim3((T * Q * 16 + 255) / 256), dim3(256), 0, st, (const float*)logit0,
                            (const float*)nullptr, T * Q, Q, K, 0.0f, 0, 1, logit0, preds);
         // criterion mean_n ||u_old - u||_F, u <- one-hot                                       (:197-199)
@@ -1652,29 +1729,21 @@ int tclip_paddle_run(const tclip_problem* pp, const float* x_q, const float* x_s
     float* cs = (float*)(ws + o_cs);
     uint8_t* live = (uint8_t*)(ws + o_live);
     float* logit0 = (float*)(ws + o_logit);
-    int32_t* rows = (int32_t*)(ws + o_rows);
-    int32_t* scratch_rows = (int32_t*)(ws + o_scratch);
-    int32_t* counts = (int32_t*)(ws + o_counts);
     // init (paddle.py:180-197): v = 0, prototypes = class means of the support set; every centroid moves every iteration
     hipLaunchKernelGGL(k_fill, dim3(ew_grid(TK)), dim3(256), 0, st, v, 0.0f, (size_t)TK);
     hipLaunchKernelGGL(k_support_stats, dim3(K, T), dim3(128), (size_t)S * sizeof(int), st, x_s, y_s, S, K, 0, sup, cnt);
     hipLaunchKernelGGL(k_div_rows, dim3(ew_grid((size_t)TK * K)), dim3(256), 0, st, (const float*)sup, (const float*)cnt,
                        (size_t)TK * K, K, w);
     TCLIP_HIP(hipMemsetAsync(live, 1, (size_t)TK, st));
-    TCLIP_HIP(hipMemsetAsync(counts, 0, 256, st));
-    hipLaunchKernelGGL(k_build_rows, dim3((TK + 255) / 256), dim3(256), 0, st, (const uint8_t*)live, (const int32_t*)nullptr,
-                       TK, 0, scratch_rows, rows, counts);
     for (int it = 0; it < p.iters; it++) {
         // u_update (:105-116): softmax_k(-1/2 ||w_k - z_q||^2 + lambd v_k / Q)
-        dispatch_E<LaunchKmeansLogits>(K, TK > 16384 ? 16384 : TK, st, (const float*)w, x_q, (const int32_t*)rows,
-                                       (const int32_t*)(counts + 1), Q, K, -0.5f, 1.0f, logit0);
+        dispatch_E<LaunchKmeansLogitsRows>(K, T, st, (const float*)w, x_q, (const uint8_t*)live, Q, K, -0.5f, 1.0f, logit0);
         hipLaunchKernelGGL(k_softmax, dim3((T * Q * 16 + 255) / 256), dim3(256), 0, st, (const float*)logit0, (const float*)v,
                            T * Q, Q, K, lambd, 0, 0, u, preds);
         // v_update (:118-124) and w_update (:142-158)
         hipLaunchKernelGGL(k_cluster_sizes, dim3((TK + 255) / 256), dim3(256), 0, st, (const float*)u, T, Q, K, 0, cs, live,
                            v, (int32_t*)nullptr);
-        hipLaunchKernelGGL(k_mstats, dim3((K + 63) / 64, K, T), dim3(64), 0, st, (const float*)u, x_q, (const float*)cs,
-                           (const uint8_t*)live, (const float*)sup, (const float*)cnt, Q, K, w, 1);
+        launch_mstats(st, (const float*)u, (const float*)x_q, (const float*)cs, (const uint8_t*)live, (const float*)sup, (const float*)cnt, T, Q, K, w, 1);
     }
     TCLIP_HIP(hipGetLastError());
     return TCLIP_OK;
@@ -1785,8 +1854,7 @@ int tclip_cluster_prototypes(int32_t T, int32_t Q, int32_t K, const float* x_q, 
     // cluster sizes of the one-hot predictions; "live" = non-empty cluster
     hipLaunchKernelGGL(k_cluster_sizes, dim3((TK + 255) / 256), dim3(256), 0, st, (const float*)hot, T, Q, K, 1, cs, live,
                        (float*)nullptr, (int32_t*)nullptr);
-    hipLaunchKernelGGL(k_mstats, dim3((K + 63) / 64, K, T), dim3(64), 0, st, (const float*)hot, x_q, (const float*)cs,
-                       (const uint8_t*)live, (const float*)nullptr, (const float*)nullptr, Q, K, dense);
+    launch_mstats(st, (const float*)hot, (const float*)x_q, (const float*)cs, (const uint8_t*)live, (const float*)nullptr, (const float*)nullptr, T, Q, K, dense, 0);
     hipLaunchKernelGGL(k_gather_prototypes, dim3(T), dim3(256), 0, st, preds, (const float*)dense, Q, K, Cmax, n_clusters,
                        cluster_ids, prototypes);
     TCLIP_HIP(hipGetLastError());
