@@ -687,16 +687,61 @@ __global__ __launch_bounds__(64 * W, (E > 8 ? TCLIP_MM_WAVES_LARGE : TCLIP_MM_WA
 //   crit = ||b'-b||_F^2 / ||b||_F^2 over all N*K*K entries of the batch;  stop if < 1e-11.
 // fp64 accumulation in a fixed order; the final arithmetic follows the reference's fp32 form
 // norm()**2 / norm()**2.  Also records the number of MM iterations executed.
+// First stage for large batches (K = 1000: 125 000 rows per batch, 2 MB of partials - one block
+// took 0.3 ms per checkpoint, on the critical path of every chunk): slice s of n_slices sums its
+// rows in a fixed order into dpart[b][s]; k_mm_decide then sums the slices in order.
+__global__ __launch_bounds__(256) void k_mm_decide_partial(const double* __restrict__ rowpart, const double* __restrict__ cache,
+                                                           const uint8_t* __restrict__ live, int rows_per_batch,
+                                                           int n_checks, int chunk, const int32_t* __restrict__ stop,
+                                                           double* __restrict__ dpart) {
+    const int b = blockIdx.y, slice = blockIdx.x, n_slices = gridDim.x;
+    if (stop[b]) return;
+    const int per = (rows_per_batch + n_slices - 1) / n_slices;
+    const int r0 = slice * per, r1 = r0 + per < rows_per_batch ? r0 + per : rows_per_batch;
+    const size_t base = (size_t)b * rows_per_batch;
+    double num = 0.0, den = 0.0;
+    for (int r = r0 + threadIdx.x; r < r1; r += blockDim.x) {
+        const size_t row = base + r;
+        if (live[row]) {
+            num += rowpart[2 * row];
+            den += rowpart[2 * row + 1];
+        } else {
+            num += cache[(row * n_checks + chunk) * 2];
+            den += cache[(row * n_checks + chunk) * 2 + 1];
+        }
+    }
+    __shared__ double sh[2][256];
+    sh[0][threadIdx.x] = num;
+    sh[1][threadIdx.x] = den;
+    __syncthreads();
+    for (int s = blockDim.x / 2; s > 0; s >>= 1) {
+        if ((int)threadIdx.x < s) {
+            sh[0][threadIdx.x] += sh[0][threadIdx.x + s];
+            sh[1][threadIdx.x] += sh[1][threadIdx.x + s];
+        }
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) {
+        dpart[((size_t)b * n_slices + slice) * 2] = sh[0][0];
+        dpart[((size_t)b * n_slices + slice) * 2 + 1] = sh[1][0];
+    }
+}
+
 __global__ __launch_bounds__(1024) void k_mm_decide(const double* __restrict__ rowpart, const double* __restrict__ cache,
                                                     const uint8_t* __restrict__ live, int rows_per_batch, int n_checks,
                                                     int chunk, int has_check, int l1, int is_last, int iter_mm,
                                                     int32_t* __restrict__ stop, int32_t* __restrict__ mm_iters_out /* [B] slot of this outer iteration, stride given */,
-                                                    int mm_stride) {
+                                                    int mm_stride, const double* __restrict__ dpart, int n_slices) {
     const int b = blockIdx.x;
     if (stop[b]) return;
     __shared__ double sh[2][1024];
     double num = 0.0, den = 0.0;
-    if (has_check) {
+    if (has_check && dpart) {
+        if ((int)threadIdx.x < n_slices) {
+            num = dpart[((size_t)b * n_slices + threadIdx.x) * 2];
+            den = dpart[((size_t)b * n_slices + threadIdx.x) * 2 + 1];
+        }
+    } else if (has_check) {
         const size_t base = (size_t)b * rows_per_batch;
         for (int r = threadIdx.x; r < rows_per_batch; r += blockDim.x) {
             const size_t row = base + r;
@@ -1190,9 +1235,10 @@ static hipEvent_t prof_event() {
     return g_prof.ev[g_prof.used++];
 }
 
+constexpr int kDecideSlices = 64;     // blocks per batch in the first stage of the stop test (large batches)
 struct Layout {
     size_t logz, y, alpha_old, beta_dead, sup, cnt, cs, live, rowc, logit0, cache, cache_len, rowpart, mm_rows,
-        live_rows, counts, stop, ratio, total;
+        live_rows, counts, stop, ratio, dpart, total;
     int n_checks;
 };
 
@@ -1224,6 +1270,7 @@ static Layout make_layout(const tclip_problem& p) {
     L.counts = take(256);
     L.stop = take((size_t)p.n_batches * 4);
     L.ratio = take(T * 4);
+    L.dpart = take((size_t)p.n_batches * kDecideSlices * 2 * sizeof(double));
     L.total = o;
     return L;
 }
@@ -1360,6 +1407,7 @@ static int enqueue_batches(const tclip_problem& p, const float* x_q, const float
     int32_t* counts = (int32_t*)(ws + L.counts);
     int32_t* stop = (int32_t*)(ws + L.stop);
     float* ratio = (float*)(ws + L.ratio);
+    double* dpart = (double*)(ws + L.dpart);
     const int n_chunks = n_chunks_of(p.iter_mm);
     const int n_checks = zs ? L.n_checks : 0;   // few-shot has no dead rows: nothing to cache
 
@@ -1421,9 +1469,14 @@ static int enqueue_batches(const tclip_problem& p, const float* x_q, const float
                 // it after chunk 0 get a few more chances before they are left to iterate every chunk
                 if (c < g_probe_chunks && c + 1 < a.n_checks) dispatch_E<LaunchMMProbe>(K, grid, st, a);
             }
+            const bool two_stage = a.has_check && N * K > 16384;
+            if (two_stage)
+                hipLaunchKernelGGL(k_mm_decide_partial, dim3(kDecideSlices, B), dim3(256), 0, st, (const double*)rowpart,
+                                   (const double*)cache, (const uint8_t*)live, N * K, a.n_checks, c, (const int32_t*)stop, dpart);
             hipLaunchKernelGGL(k_mm_decide, dim3(B), dim3(1024), 0, st, (const double*)rowpart, (const double*)cache,
                                (const uint8_t*)live, N * K, a.n_checks, c, a.has_check, a.l1, c == n_chunks - 1 ? 1 : 0,
-                               p.iter_mm, stop, mm_iters + it, p.iters);
+                               p.iter_mm, stop, mm_iters + it, p.iters, (const double*)(two_stage ? dpart : nullptr),
+                               kDecideSlices);
         }
         // ---- E-step for the rows whose alpha changed, softmax over all classes
         {
