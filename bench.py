@@ -43,6 +43,8 @@ ITER_MM = 1000
 FLOP_EQ_PER_UPDATE = 48.0
 PEAK_VALU_TFLOPS = 157.3
 PEAK_HBM_GBS = 8000.0
+LANE_INSTR_PER_UPDATE = 361.0     # measured: SQ_INSTS_VALU 1.1417e11 x 64 lanes / 2.026e10 element-updates (profiles/r01_pmc_small_workload.txt)
+PEAK_LANE_INSTR_T = 39.3          # 256 CUs x 4 SIMDs x 16 lanes x 2.4 GHz, in 1e12 lane-instructions/s
 
 
 _CPU_SNIPPET = r"""
@@ -166,6 +168,13 @@ def main():
                          "kernel_busy_ms_per_step": mm_ms / steps, "launches_per_step": mm_launches / steps,
                          "avg_launch_ms": mm_launch_sum / max(mm_launches, 1),
                          "launch_overlap": mm_launch_sum / mm_ms if mm_ms > 0 else 0.0,
+                         # the same launches against the VALU ISSUE rate: lane-instructions per update is a
+                         # PMC measurement (SQ_INSTS_VALU x 64 / updates, profiles/r01_pmc_small_workload.txt),
+                         # the peak is one wave64 VALU instruction per SIMD every 4 cycles at 2.4 GHz
+                         "valu_issue": {"achieved": LANE_INSTR_PER_UPDATE * updates / (mm_ms * 1e-3) / 1e12 if mm_ms > 0 else 0.0,
+                                        "peak": PEAK_LANE_INSTR_T, "unit": "T lane-instr/s",
+                                        "frac": (LANE_INSTR_PER_UPDATE * updates / (mm_ms * 1e-3) / 1e12) / PEAK_LANE_INSTR_T if mm_ms > 0 else 0.0,
+                                        "lane_instructions_per_update": LANE_INSTR_PER_UPDATE},
                          # the same launches against the HBM roofline (north_star asks for it; the
                          # kernel keeps rows in registers for 50 iterations, so this is tiny by design)
                          "hbm": {"bound": "hbm", "achieved": rows_bytes / (mm_ms * 1e-3) / 1e9 if mm_ms > 0 else 0.0,
