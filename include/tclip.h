@@ -125,6 +125,13 @@ size_t tclip_hard_kmeans_workspace_bytes(const tclip_problem* p);
 int tclip_hard_kmeans_run(const tclip_problem* p, const float* x_q, float* u, float* w, int32_t* preds,
                           float* criterions, void* workspace, size_t workspace_bytes, void* stream);
 
+/* KL_KMEANS on probability features (reference: src/methods/zero_shot/kl_kmeans.py:123-189):
+ * centroids w = (u^T z) / max(sum_q u, 1) with empty clusters at zero, every query assigned to the
+ * centroid of smallest KL(z + eps || w + eps) (first minimum).  Problem fields, outputs and
+ * workspace (tclip_hard_kmeans_workspace_bytes) as for HARD_KMEANS. */
+int tclip_kl_kmeans_run(const tclip_problem* p, const float* x_q, float* u, float* w, int32_t* preds,
+                        float* criterions, void* workspace, size_t workspace_bytes, void* stream);
+
 /* PADDLE on probability features (reference: src/methods/few_shot/paddle.py:94-219; feature
  * dimension = n_class).  Prototypes start as the class means of the support set; each iteration:
  * u = softmax_k(-1/2 ||w_k - z_q||^2 + lambd v_k / Q), v = log(mean_q u + eps) + 1,

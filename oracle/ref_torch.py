@@ -277,3 +277,33 @@ def run_em_gaussian(x_q, *, n_class, iters, temperature, lambd):
         criterions.append((u.clone() - u).norm(dim=(1, 2)).mean(0))
     return {"u": u, "v": v, "w": w, "criterions": torch.stack(criterions), "argmax": torch.stack(argmax),
             "seconds": time.time() - t0}
+
+
+def run_kl_kmeans(x_q, *, n_class, iters):
+    """KL_KMEANS on probability features, the reference's torch op sequence
+    (src/methods/zero_shot/kl_kmeans.py:123-189): centroids w = (u^T z) / max(sum u, 1) (a bmm),
+    zero for empty clusters; every query goes to the centroid of smallest
+    KL(z + eps || w + eps) = sum_d P log(P / Q).  Returns dict(u, w, criterions (iters,),
+    labels (iters,N,Q), seconds); the reference logs every criterion twice."""
+    query = x_q.clone().float()
+    t0 = time.time()
+    u = query.clone()
+    u_old = u.clone()
+    criterions, labels_all = [], []
+    w = None
+    for _ in range(iters):
+        cluster_sizes = u.sum(1).unsqueeze(-1)
+        nonzero = cluster_sizes > 0
+        w = (u.transpose(1, 2) @ query) / cluster_sizes.clamp(min=1)
+        w *= nonzero.float()
+        P = query.unsqueeze(2) + EPS
+        Qm = w.unsqueeze(1) + EPS
+        divs = torch.sum(P * torch.log(P / Qm), dim=-1)
+        labels = torch.argmin(divs, dim=-1)
+        u = torch.zeros_like(u)
+        u.scatter_(2, labels.unsqueeze(-1), 1.0)
+        labels_all.append(labels.clone())
+        criterions.append((u_old - u).norm(dim=(1, 2)).mean(0))
+        u_old = u.clone()
+    return {"u": u, "w": w, "criterions": torch.stack(criterions), "labels": torch.stack(labels_all),
+            "seconds": time.time() - t0}

@@ -55,9 +55,10 @@ def load_reference_classes():
     from src.methods.zero_shot.hard_kmeans import HARD_KMEANS as HKM
     from src.methods.few_shot.paddle import PADDLE
     from src.methods.zero_shot.em_gaussian import EM_GAUSSIAN as EMG
+    from src.methods.zero_shot.kl_kmeans import KL_KMEANS as KLK
     sys.path.pop(0)
     return {"zs_soft": ZS, "zs_hard": ZSH, "fs_soft": FS, "fs_hard": FSH, "zs_skm": SKM, "zs_hkm": HKM,
-            "fs_paddle": PADDLE, "zs_emg": EMG}
+            "fs_paddle": PADDLE, "zs_emg": EMG, "zs_klk": KLK}
 
 
 # PADDLE's lambd is a tunable float (paddle.yaml: 0.0); the fixtures also use a value that makes the
@@ -97,6 +98,12 @@ SMALL = {
     "zs_hkm_K5_N4": ("zs_hkm", 5, 4, 20, 0, 2037, True),
     "zs_emg_K7_N4": ("zs_emg", 7, 4, 20, 0, 2038, True),
     "fs_paddle_K5_N3_s2": ("fs_paddle", 5, 3, 20, 2, 2039, True),
+    "zs_klk_K2_N4": ("zs_klk", 2, 4, 10, 0, 2040, True),
+    "zs_klk_K7_N4": ("zs_klk", 7, 4, 10, 0, 2041, True),
+    "zs_klk_K10_N4": ("zs_klk", 10, 4, 10, 0, 2020, True),
+    "zs_klk_K37_N6": ("zs_klk", 37, 6, 10, 0, 2021, True),
+    "zs_klk_K100_N4": ("zs_klk", 100, 4, 10, 0, 2022, True),
+    "zs_klk_K397_N1": ("zs_klk", 397, 1, 10, 0, 2023, True),
     "zs_emg_K10_N4": ("zs_emg", 10, 4, 20, 0, 2020, True),
     "zs_emg_K37_N6": ("zs_emg", 37, 6, 20, 0, 2021, True),
     "zs_emg_K100_N4": ("zs_emg", 100, 4, 20, 0, 2022, True),
@@ -145,7 +152,7 @@ def run_case(name, spec, classes):
             norm_vals.append(float(r))
         return r
 
-    is_skm = kind in ("zs_skm", "zs_hkm", "fs_paddle", "zs_emg")      # k-means family: no MM loop, the centroids stand in for alpha
+    is_skm = kind in ("zs_skm", "zs_hkm", "fs_paddle", "zs_emg", "zs_klk")      # k-means family: no MM loop, the centroids stand in for alpha
     real_update_alpha = None if is_skm else m.update_alpha
 
     def traced_update_alpha(alpha_0, y_cst):
@@ -159,16 +166,25 @@ def run_case(name, spec, classes):
         row[:len(nv)] = nv
         trace["stop_test"].append(row)
 
-    real_u_update = m.u_update
+    if kind == "zs_klk":             # KL_KMEANS has no u_update: its assignment is the argmin of kl_divergence (kl_kmeans.py:172-173)
+        real_kl = m.kl_divergence
 
-    def traced_u_update(q):
-        real_u_update(q)
-        pick = m.u.argmin(2) if kind == "zs_hkm" else m.u.argmax(2)     # HARD_KMEANS assigns by argmin (hard_kmeans.py:193)
-        trace["argmax"].append(pick.to(torch.int16).numpy().copy())
+        def traced_kl(P, Q):
+            divs = real_kl(P, Q)
+            trace["argmax"].append(divs.argmin(-1).to(torch.int16).numpy().copy())
+            return divs
+        m.kl_divergence = traced_kl
+    else:
+        real_u_update = m.u_update
+
+        def traced_u_update(q):
+            real_u_update(q)
+            pick = m.u.argmin(2) if kind == "zs_hkm" else m.u.argmax(2)     # HARD_KMEANS assigns by argmin (hard_kmeans.py:193)
+            trace["argmax"].append(pick.to(torch.int16).numpy().copy())
+        m.u_update = traced_u_update
 
     if not is_skm:
         m.update_alpha = traced_update_alpha
-    m.u_update = traced_u_update
     torch.sqrt = counting_sqrt
     torch.norm = recording_norm
     t0 = time.time()

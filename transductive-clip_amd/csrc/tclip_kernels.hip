@@ -996,6 +996,86 @@ __global__ void k_div_rows(const float* __restrict__ num, const float* __restric
         out[i] = num[i] / den[i / K];
 }
 
+// KL_KMEANS (kl_kmeans.py:123-189).  Centroids: w = (u^T z) / max(sum_q u, 1), zero for empty clusters.
+// torch's bmm is MKL sgemm, which for these shapes accumulates every output as one chain of fused
+// multiply-adds over the queries in ascending order (probed against torch on soft and one-hot u:
+// identical on every entry), so a thread keeps kMstatsRows such chains for its feature column.
+__global__ __launch_bounds__(64) void k_kl_centroids(const float* __restrict__ u, const float* __restrict__ z,
+                                                     const float* __restrict__ cs, int Q, int K, float* __restrict__ w) {
+    const int t = blockIdx.z, k0 = blockIdx.y * kMstatsRows;
+    const int d = blockIdx.x * blockDim.x + threadIdx.x;
+    if (d >= K) return;
+    const float* ut = u + (size_t)t * Q * K;
+    const float* zt = z + (size_t)t * Q * K + d;
+    float acc[kMstatsRows];
+#pragma unroll
+    for (int j = 0; j < kMstatsRows; j++) acc[j] = 0.0f;
+    for (int q = 0; q < Q; q++) {
+        const float zv = zt[(size_t)q * K];
+#pragma unroll
+        for (int j = 0; j < kMstatsRows; j++) {
+            const int k = k0 + j < K ? k0 + j : K - 1;
+            acc[j] = __builtin_fmaf(ut[(size_t)q * K + k], zv, acc[j]);
+        }
+    }
+#pragma unroll
+    for (int j = 0; j < kMstatsRows; j++) {
+        if (k0 + j >= K) break;
+        const size_t row = (size_t)t * K + k0 + j;
+        const float c = cs[row];
+        w[row * K + d] = (acc[j] / (c < 1.0f ? 1.0f : c)) * (c > 0.0f ? 1.0f : 0.0f);
+    }
+}
+
+// divs[t,q,k] = sum_d P log(P / Q), P = z[t,q,d] + eps, Q = w[t,k,d] + eps, the sum in torch's last-dim
+// order (kl_kmeans.py:123-127); same blocking as k_kmeans_logits_rows.
+template <int E, int kRowsPerBlock>
+__global__ __launch_bounds__(256) void k_kl_divergences(const float* __restrict__ w, const float* __restrict__ z, int Q, int K,
+                                                        float* __restrict__ divs) {
+    const int lane = threadIdx.x & (kGroup - 1);
+    const int group = threadIdx.x / kGroup, groups_per_block = blockDim.x / kGroup;
+    const int t = blockIdx.y, k0 = blockIdx.x * kRowsPerBlock;
+    float qv[kRowsPerBlock][E];
+#pragma unroll
+    for (int j = 0; j < kRowsPerBlock; j++) {
+#pragma unroll
+        for (int e = 0; e < E; e++) {
+            const int d = e * kGroup + lane;
+            qv[j][e] = (k0 + j < K && d < K) ? w[((size_t)t * K + k0 + j) * K + d] + kEpsF : 1.0f;
+        }
+    }
+    for (int q = group; q < Q; q += groups_per_block) {
+        const float* zq = z + ((size_t)t * Q + q) * K;
+        float pv[E];
+#pragma unroll
+        for (int e = 0; e < E; e++) {
+            const int d = e * kGroup + lane;
+            pv[e] = d < K ? zq[d] + kEpsF : 1.0f;
+        }
+#pragma unroll
+        for (int j = 0; j < kRowsPerBlock; j++) {
+            if (k0 + j >= K) break;                                  // block-uniform
+            float pr[E];
+#pragma unroll
+            for (int e = 0; e < E; e++) pr[e] = e * kGroup + lane < K ? pv[e] * log_f32(pv[e] / qv[j][e]) : 0.0f;
+            const float ssum = group_sum_torch<E>(pr, K, lane);
+            if (lane == 0) divs[((size_t)t * Q + q) * K + k0 + j] = ssum;
+        }
+    }
+}
+
+// labels[r] = first index of the smallest of the K values of row r (torch.argmin).
+__global__ void k_argmin_rows(const float* __restrict__ x, int rows, int K, int32_t* __restrict__ labels) {
+    const int r = blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= rows) return;
+    const float* xr = x + (size_t)r * K;
+    float best = xr[0];
+    int best_k = 0;
+    for (int k = 1; k < K; k++)
+        if (xr[k] < best) { best = xr[k]; best_k = k; }
+    labels[r] = best_k;
+}
+
 // HARD_KMEANS helpers.  Centroids of empty clusters are zero (hard_kmeans.py:149-152).
 __global__ void k_zero_dead_rows(const uint8_t* __restrict__ live, int TK, int K, float* __restrict__ w) {
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < (size_t)TK * K; i += (size_t)gridDim.x * blockDim.x)
@@ -1337,6 +1417,12 @@ template <int E> struct LaunchLogits {
     }
 };
 
+template <int E> struct LaunchKlDivergences {
+    static void run(int T, hipStream_t st, const float* w, const float* z, int Q, int K, float* divs) {
+        constexpr int kRows = E <= 16 ? 4 : 2;
+        hipLaunchKernelGGL((k_kl_divergences<E, kRows>), dim3((K + kRows - 1) / kRows, T), dim3(256), 0, st, w, z, Q, K, divs);
+    }
+};
 template <int E> struct LaunchKmeansLogitsRows {
     static void run(int T, hipStream_t st, const float* w, const float* z, const uint8_t* need, int Q, int K, float pre,
                     float temperature, float* logit0) {
@@ -1797,6 +1883,39 @@ int tclip_paddle_run(const tclip_problem* pp, const float* x_q, const float* x_s
         hipLaunchKernelGGL(k_cluster_sizes, dim3((TK + 255) / 256), dim3(256), 0, st, (const float*)u, T, Q, K, 0, cs, live,
                            v, (int32_t*)nullptr);
         launch_mstats(st, (const float*)u, (const float*)x_q, (const float*)cs, (const uint8_t*)live, (const float*)sup, (const float*)cnt, T, Q, K, w, 1);
+    }
+    TCLIP_HIP(hipGetLastError());
+    return TCLIP_OK;
+}
+
+int tclip_kl_kmeans_run(const tclip_problem* pp, const float* x_q, float* u, float* w, int32_t* preds,
+                        float* criterions, void* workspace, size_t workspace_bytes, void* stream) {
+    if (int rc = check_problem(pp)) return rc;
+    const tclip_problem p = *pp;
+    if (!x_q || !u || !w || !preds || !criterions || !workspace) return fail(TCLIP_ERR_ARG, "null pointer argument");
+    if (p.n_support != 0) return fail(TCLIP_ERR_ARG, "KL_KMEANS is a zero-shot method: n_support must be 0");
+    size_t o_cs, o_live, o_ones, o_logit, o_rows, o_scratch, o_counts;
+    const size_t o_change = kmeans_ws_parts(p, &o_cs, &o_live, &o_ones, &o_logit, &o_rows, &o_scratch, &o_counts);
+    if (workspace_bytes < tclip_hard_kmeans_workspace_bytes(pp)) return fail(TCLIP_ERR_WORKSPACE, "workspace smaller than tclip_hard_kmeans_workspace_bytes()");
+    if (((uintptr_t)workspace & 255) != 0) return fail(TCLIP_ERR_WORKSPACE, "workspace must be 256-byte aligned");
+    hipStream_t st = (hipStream_t)stream;
+    char* ws = (char*)workspace;
+    const int Q = p.n_query, K = p.n_class, B = p.n_batches, N = p.tasks_per_batch, T = B * N, TK = T * K;
+    const size_t TQK = (size_t)T * Q * K;
+    float* cs = (float*)(ws + o_cs);
+    uint8_t* live = (uint8_t*)(ws + o_live);
+    float* divs = (float*)(ws + o_logit);
+    float* change = (float*)(ws + o_change);
+    hipLaunchKernelGGL(k_copy, dim3(ew_grid(TQK)), dim3(256), 0, st, x_q, u, TQK);          // u = z
+    for (int it = 0; it < p.iters; it++) {
+        hipLaunchKernelGGL(k_cluster_sizes, dim3((TK + 255) / 256), dim3(256), 0, st, (const float*)u, T, Q, K, 1, cs,
+                           live, (float*)nullptr, (int32_t*)nullptr);
+        hipLaunchKernelGGL(k_kl_centroids, dim3((K + 63) / 64, (K + kMstatsRows - 1) / kMstatsRows, T), dim3(64), 0, st,
+                           (const float*)u, x_q, (const float*)cs, Q, K, w);
+        dispatch_E<LaunchKlDivergences>(K, T, st, (const float*)w, x_q, Q, K, divs);
+        hipLaunchKernelGGL(k_argmin_rows, dim3((T * Q + 255) / 256), dim3(256), 0, st, (const float*)divs, T * Q, K, preds);
+        hipLaunchKernelGGL(k_hard_assign, dim3(T), dim3(256), 0, st, (const int32_t*)preds, Q, K, u, change);
+        hipLaunchKernelGGL(k_criterion_mean, dim3(B), dim3(64), 0, st, (const float*)change, N, 0, criterions + it, p.iters);
     }
     TCLIP_HIP(hipGetLastError());
     return TCLIP_OK;

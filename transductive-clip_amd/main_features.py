@@ -36,6 +36,7 @@ METHOD_DEFAULTS = {
     "hard_em_dirichlet": dict(name_method="HARD_EM_DIRICHLET", iter=10, iter_mm=1000, graph_matching=True, tunable=False),
     "soft_kmeans": dict(name_method="SOFT_KMEANS", iter=20, graph_matching=True, tunable=False),
     "hard_kmeans": dict(name_method="HARD_KMEANS", iter=10, graph_matching=True, tunable=False),
+    "kl_kmeans": dict(name_method="KL_KMEANS", iter=10, graph_matching=True, tunable=False),
     "em_gaussian": dict(name_method="EM_GAUSSIAN", iter=20, graph_matching=True, tunable=False),
     "paddle": dict(name_method="PADDLE", iter=20, lambd=0.0, tunable=True),
 }

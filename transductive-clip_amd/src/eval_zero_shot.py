@@ -14,13 +14,14 @@ from src.methods.zero_shot.em_dirichlet import EM_DIRICHLET
 from src.methods.zero_shot.hard_em_dirichlet import HARD_EM_DIRICHLET
 from src.methods.zero_shot.em_gaussian import EM_GAUSSIAN
 from src.methods.zero_shot.hard_kmeans import HARD_KMEANS
+from src.methods.zero_shot.kl_kmeans import KL_KMEANS
 from src.methods.zero_shot.soft_kmeans import SOFT_KMEANS
 from src.sampler_zero_shot import CategoriesSampler_zero_shot, SamplerQuery_zero_shot
 from src.utils import Logger, compute_confidence_interval
 from tclip_amd import engine, sharding
 
 _METHODS = {'EM_DIRICHLET': EM_DIRICHLET, 'HARD_EM_DIRICHLET': HARD_EM_DIRICHLET, 'SOFT_KMEANS': SOFT_KMEANS,
-            'HARD_KMEANS': HARD_KMEANS, 'EM_GAUSSIAN': EM_GAUSSIAN}
+            'HARD_KMEANS': HARD_KMEANS, 'EM_GAUSSIAN': EM_GAUSSIAN, 'KL_KMEANS': KL_KMEANS}
 
 
 class Evaluator_zero_shot:

@@ -122,7 +122,12 @@ def run_em_gaussian(x_q, *, iters, temperature, lambd):
     return u, v, w, preds
 
 
-def run_hard_kmeans(x_q, *, iters, n_batches=1):
+def run_kl_kmeans(x_q, *, iters, n_batches=1):
+    """KL_KMEANS: same outputs as run_hard_kmeans."""
+    return run_hard_kmeans(x_q, iters=iters, n_batches=n_batches, _entry="tclip_kl_kmeans_run")
+
+
+def run_hard_kmeans(x_q, *, iters, n_batches=1, _entry="tclip_hard_kmeans_run"):
     """HARD_KMEANS: x_q (T,Q,K) f32 cuda -> (u one-hot (T,Q,K), w (T,K,K), preds (T,Q) i32,
     criterions (n_batches, iters)), cuda, not synchronised."""
     _require_cuda(x_q, "x_q")
@@ -143,9 +148,9 @@ def run_hard_kmeans(x_q, *, iters, n_batches=1):
         w = torch.empty(T, K, K, device=dev)
         preds = torch.empty(T, Q, dtype=torch.int32, device=dev)
         crit = torch.empty(n_batches, iters, device=dev)
-        rc = lib.tclip_hard_kmeans_run(ctypes.byref(p), _ptr(x_q), _ptr(u), _ptr(w), _ptr(preds), _ptr(crit),
-                                       ctypes.c_void_p(ws.data_ptr() + off), ws_bytes, _stream())
-        _capi.check(rc, "tclip_hard_kmeans_run")
+        rc = getattr(lib, _entry)(ctypes.byref(p), _ptr(x_q), _ptr(u), _ptr(w), _ptr(preds), _ptr(crit),
+                                  ctypes.c_void_p(ws.data_ptr() + off), ws_bytes, _stream())
+        _capi.check(rc, _entry)
         ws.record_stream(torch.cuda.current_stream())
     return u, w, preds, crit
 
