@@ -114,6 +114,15 @@ int tclip_soft_kmeans_run(const tclip_problem* p, const float* x_q, float temper
 int tclip_em_gaussian_run(const tclip_problem* p, const float* x_q, float temperature, float* u, float* v, float* w,
                           int32_t* preds, void* workspace, size_t workspace_bytes, void* stream);
 
+/* EM_GAUSSIAN_COV on probability features (reference: src/methods/zero_shot/em_gaussian_cov.py:106-257):
+ * EM_GAUSSIAN with a diagonal inverse covariance per cluster and no temperature,
+ *   s = sum_q u / max(sum_q u (w - z_q)^2, eps)   (empty clusters keep w and s),
+ *   u = softmax_k(-1/2 sum_d s (w - z)^2 + 1/2 sum_d log(s + eps) + lambd v_k / Q).
+ * Same problem fields and workspace (tclip_soft_kmeans_workspace_bytes) as EM_GAUSSIAN;
+ * s device [T,K,K] out. */
+int tclip_em_gaussian_cov_run(const tclip_problem* p, const float* x_q, float* u, float* v, float* w, float* s,
+                              int32_t* preds, void* workspace, size_t workspace_bytes, void* stream);
+
 /* HARD_KMEANS on probability features (reference: src/methods/zero_shot/hard_kmeans.py:26-35,
  * 128-152, 186-204): centroids = means of the members, zero for empty clusters;
  * u = one_hot(argmin_k softmax_k ||w_k - z_q||^2) (first minimum).  Same problem fields as

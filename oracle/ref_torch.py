@@ -279,6 +279,41 @@ def run_em_gaussian(x_q, *, n_class, iters, temperature, lambd):
             "seconds": time.time() - t0}
 
 
+def run_em_gaussian_cov(x_q, *, n_class, iters, lambd):
+    """EM_GAUSSIAN_COV on probability features, the reference's torch op sequence
+    (src/methods/zero_shot/em_gaussian_cov.py:106-257): EM_GAUSSIAN with a diagonal inverse
+    covariance s per cluster, s = sum_q u / clamp(sum_q u (w - z_q)^2, eps),
+    u = softmax_k(-1/2 sum_d s (w - z)^2 + 1/2 sum_d log(s + eps) + lambd v_k / Q); no temperature.
+    Returns dict(u, v, w, s, criterions, argmax (iters,N,Q), seconds)."""
+    query = x_q.clone().float()
+    n_task, n_query = query.shape[0], query.shape[1]
+    t0 = time.time()
+    v = torch.zeros(n_task, n_class)
+    u = query.clone()
+    num = (query.unsqueeze(2) * u.unsqueeze(3)).sum(1)
+    den = u.sum(1).clamp(min=EPS)
+    w = num.div_(den.unsqueeze(2))
+    d_q = ((w.unsqueeze(1) - query.unsqueeze(2)).square_()).mul_(u.unsqueeze(3)).sum(1)
+    s = (u.sum(1)).unsqueeze(2) / d_q.clamp(min=EPS)
+    criterions, argmax = [], []
+    for _ in range(iters):
+        num = (query.unsqueeze(2) * u.unsqueeze(3)).sum(1)
+        den = u.sum(1).clamp(min=EPS)
+        live = u.sum(1).unsqueeze(-1) > EPS
+        w = num.div_(den.unsqueeze(2)) * live + (w * (1 - 1 * live))
+        d_q = ((w.unsqueeze(1) - query.unsqueeze(2)).square_()).mul_(u.unsqueeze(3)).sum(1)
+        s = (u.sum(1)).unsqueeze(2) / d_q.clamp(min=EPS) * live + (s * (1 - 1 * live))
+        diff = w.unsqueeze(1) - query.unsqueeze(2)
+        logits = -1 / 2 * ((diff.square_()).mul_(s.unsqueeze(1))).sum(dim=-1)
+        det = 1 / 2 * (torch.log(s + EPS).sum(-1)).unsqueeze(1)
+        u = (logits + det + lambd * v.unsqueeze(1) / n_query).softmax(2)
+        argmax.append(u.argmax(2).clone())
+        v = torch.log(u.sum(1) / u.size(1) + EPS) + 1
+        criterions.append((u.clone() - u).norm(dim=(1, 2)).mean(0))
+    return {"u": u, "v": v, "w": w, "s": s, "criterions": torch.stack(criterions), "argmax": torch.stack(argmax),
+            "seconds": time.time() - t0}
+
+
 def run_kl_kmeans(x_q, *, n_class, iters):
     """KL_KMEANS on probability features, the reference's torch op sequence
     (src/methods/zero_shot/kl_kmeans.py:123-189): centroids w = (u^T z) / max(sum u, 1) (a bmm),

@@ -56,9 +56,10 @@ def load_reference_classes():
     from src.methods.few_shot.paddle import PADDLE
     from src.methods.zero_shot.em_gaussian import EM_GAUSSIAN as EMG
     from src.methods.zero_shot.kl_kmeans import KL_KMEANS as KLK
+    from src.methods.zero_shot.em_gaussian_cov import EM_GAUSSIAN_COV as EMGC
     sys.path.pop(0)
     return {"zs_soft": ZS, "zs_hard": ZSH, "fs_soft": FS, "fs_hard": FSH, "zs_skm": SKM, "zs_hkm": HKM,
-            "fs_paddle": PADDLE, "zs_emg": EMG, "zs_klk": KLK}
+            "fs_paddle": PADDLE, "zs_emg": EMG, "zs_klk": KLK, "zs_emgc": EMGC}
 
 
 # PADDLE's lambd is a tunable float (paddle.yaml: 0.0); the fixtures also use a value that makes the
@@ -104,6 +105,12 @@ SMALL = {
     "zs_klk_K37_N6": ("zs_klk", 37, 6, 10, 0, 2021, True),
     "zs_klk_K100_N4": ("zs_klk", 100, 4, 10, 0, 2022, True),
     "zs_klk_K397_N1": ("zs_klk", 397, 1, 10, 0, 2023, True),
+    "zs_emgc_K2_N4": ("zs_emgc", 2, 4, 20, 0, 2051, True),
+    "zs_emgc_K7_N4": ("zs_emgc", 7, 4, 20, 0, 2052, True),
+    "zs_emgc_K10_N4": ("zs_emgc", 10, 4, 20, 0, 2020, True),
+    "zs_emgc_K37_N6": ("zs_emgc", 37, 6, 20, 0, 2021, True),
+    "zs_emgc_K100_N4": ("zs_emgc", 100, 4, 20, 0, 2022, True),
+    "zs_emgc_K397_N1": ("zs_emgc", 397, 1, 20, 0, 2023, True),
     "zs_emg_K10_N4": ("zs_emg", 10, 4, 20, 0, 2020, True),
     "zs_emg_K37_N6": ("zs_emg", 37, 6, 20, 0, 2021, True),
     "zs_emg_K100_N4": ("zs_emg", 100, 4, 20, 0, 2022, True),
@@ -152,7 +159,7 @@ def run_case(name, spec, classes):
             norm_vals.append(float(r))
         return r
 
-    is_skm = kind in ("zs_skm", "zs_hkm", "fs_paddle", "zs_emg", "zs_klk")      # k-means family: no MM loop, the centroids stand in for alpha
+    is_skm = kind in ("zs_skm", "zs_hkm", "fs_paddle", "zs_emg", "zs_klk", "zs_emgc")      # k-means family: no MM loop, the centroids stand in for alpha
     real_update_alpha = None if is_skm else m.update_alpha
 
     def traced_update_alpha(alpha_0, y_cst):
@@ -211,6 +218,8 @@ def run_case(name, spec, classes):
     }
     if few:
         out["x_s"], out["y_s"] = x_s.numpy(), y_s.numpy()
+    if kind == "zs_emgc":
+        out["s"] = m.s.numpy()        # inverse diagonal covariances
     if full:
         out["alpha"] = alpha
         out["u"] = m.u.numpy()

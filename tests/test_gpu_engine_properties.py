@@ -190,7 +190,7 @@ def test_full_size_properties_k100_batch100():
 
 
 @pytest.mark.parametrize("name", ["eval_zs_soft_K10", "eval_zs_hard_K10", "eval_fs_soft_K10", "eval_zs_soft_kmeans_K10",
-                                  "eval_zs_hard_kmeans_K10", "eval_zs_em_gaussian_K10", "eval_zs_kl_kmeans_K10",
+                                  "eval_zs_hard_kmeans_K10", "eval_zs_em_gaussian_K10", "eval_zs_em_gaussian_cov_K10", "eval_zs_kl_kmeans_K10",
                                   "eval_fs_paddle_K10"])
 def test_task_batch_loop_matches_reference(name):
     """evaluate_tasks on the seeded synthetic table: the reference's mean accuracy (fixtures made

@@ -194,19 +194,31 @@ __global__ void k_cluster_sizes(const float* __restrict__ u, int T, int Q, int K
 //          = (sum_q u f + sup[t,k,d]) / (cs[t,k] + cnt[t,k])                 (PADDLE centroids)
 // The same kernel, with f = raw features and u = one-hot predictions, gives the cluster
 // prototypes of the accuracy tail (em_dirichlet.py:66-67).
+// kCov: the inverse diagonal covariances of EM_GAUSSIAN_COV (em_gaussian_cov.py:172-193),
+//          y[t,k,d] = cs[t,k] / max(sum_q (wc[t,k,d] - f[t,q,d])^2 * u[t,q,k], eps)
+template <bool kCov>
 __global__ void k_mstats(const float* __restrict__ u, const float* __restrict__ f, const float* __restrict__ cs,
                          const uint8_t* __restrict__ live, const float* __restrict__ sup,
-                         const float* __restrict__ cnt, int Q, int K, float* __restrict__ y, int paddle, int k_first) {
+                         const float* __restrict__ cnt, int Q, int K, float* __restrict__ y, int paddle, int k_first,
+                         const float* __restrict__ wc) {
     const int t = blockIdx.z, k = blockIdx.y + k_first;
     const int d = blockIdx.x * blockDim.x + threadIdx.x;
     const size_t row = (size_t)t * K + k;
     if (d >= K || !live[row]) return;
     const float* ut = u + (size_t)t * Q * K + k;
     const float* ft = f + (size_t)t * Q * K + d;
-    float s = dsum_outer(Q, (long)k * K + d, (long)K * K,
-                         [&](int q) { return ut[(size_t)q * K] * ft[(size_t)q * K]; });
+    const float wcv = kCov ? wc[row * K + d] : 0.0f;
+    float s = dsum_outer(Q, (long)k * K + d, (long)K * K, [&](int q) {
+        if (kCov) {
+            const float df = wcv - ft[(size_t)q * K];
+            return (df * df) * ut[(size_t)q * K];
+        }
+        return ut[(size_t)q * K] * ft[(size_t)q * K];
+    });
     const float c = cs[row];
-    if (sup && paddle) {           // PADDLE centroid (few_shot/paddle.py:154-158): (sum_q u z + support sum) / (sum_q u + count)
+    if (kCov) {
+        y[row * K + d] = c / (s < kEpsF ? kEpsF : s);
+    } else if (sup && paddle) {           // PADDLE centroid (few_shot/paddle.py:154-158): (sum_q u z + support sum) / (sum_q u + count)
         y[row * K + d] = (s + sup[row * K + d]) / (c + cnt[row]);
     } else if (sup) {
         const float w = 1.0f / (cnt[row] + c);
@@ -221,15 +233,26 @@ __global__ void k_mstats(const float* __restrict__ u, const float* __restrict__ 
 // from L2 once per 8 classes instead of once per class, the u values are wave-uniform loads, and
 // each output keeps its own cascade state, so the sums are the ones dsum_cascade builds.
 constexpr int kMstatsRows = 8;
+template <bool kCov>
 __global__ __launch_bounds__(64) void k_mstats_rows(const float* __restrict__ u, const float* __restrict__ f,
                                                     const float* __restrict__ cs, const uint8_t* __restrict__ live,
                                                     const float* __restrict__ sup, const float* __restrict__ cnt, int Q,
-                                                    int K, float* __restrict__ y, int paddle) {
+                                                    int K, float* __restrict__ y, int paddle, const float* __restrict__ wc) {
     const int t = blockIdx.z, k0 = blockIdx.y * kMstatsRows;
     const int d = blockIdx.x * blockDim.x + threadIdx.x;
     if (d >= K) return;
     const float* ut = u + (size_t)t * Q * K + k0;
     const float* ft = f + (size_t)t * Q * K + d;
+    float wcv[kMstatsRows];
+#pragma unroll
+    for (int j = 0; j < kMstatsRows; j++) wcv[j] = kCov ? wc[((size_t)t * K + k0 + j) * K + d] : 0.0f;
+    auto term = [&](int j, float uv, float fv) {
+        if (kCov) {
+            const float df = wcv[j] - fv;
+            return (df * df) * uv;
+        }
+        return uv * fv;
+    };
     const int cl = dev_ceil_log2(Q) / 4;
     const int level_power = cl > 4 ? cl : 4;
     const int step = 1 << level_power, mask = step - 1;
@@ -241,7 +264,7 @@ __global__ __launch_bounds__(64) void k_mstats_rows(const float* __restrict__ u,
         for (int jj = 0; jj < step; ++jj, ++i) {
             const float fv = ft[(size_t)i * K];
 #pragma unroll
-            for (int j = 0; j < kMstatsRows; j++) a0[j] += ut[(size_t)i * K + j] * fv;
+            for (int j = 0; j < kMstatsRows; j++) a0[j] += term(j, ut[(size_t)i * K + j], fv);
         }
         const bool l2 = (i & (mask << level_power)) == 0, l3 = l2 && (i & (mask << (2 * level_power))) == 0;
 #pragma unroll
@@ -254,7 +277,7 @@ __global__ __launch_bounds__(64) void k_mstats_rows(const float* __restrict__ u,
     for (; i < Q; ++i) {
         const float fv = ft[(size_t)i * K];
 #pragma unroll
-        for (int j = 0; j < kMstatsRows; j++) a0[j] += ut[(size_t)i * K + j] * fv;
+        for (int j = 0; j < kMstatsRows; j++) a0[j] += term(j, ut[(size_t)i * K + j], fv);
     }
 #pragma unroll
     for (int j = 0; j < kMstatsRows; j++) {
@@ -265,7 +288,9 @@ __global__ __launch_bounds__(64) void k_mstats_rows(const float* __restrict__ u,
         s += a2[j];
         s += a3[j];
         const float c = cs[row];
-        if (sup && paddle) {
+        if (kCov) {
+            y[row * K + d] = c / (s < kEpsF ? kEpsF : s);
+        } else if (sup && paddle) {
             y[row * K + d] = (s + sup[row * K + d]) / (c + cnt[row]);
         } else if (sup) {
             const float w = 1.0f / (cnt[row] + c);
@@ -889,6 +914,58 @@ __global__ __launch_bounds__(256) void k_kmeans_logits_rows(const float* __restr
     }
 }
 
+// EM_GAUSSIAN_COV E-step (em_gaussian_cov.py:106-129):
+//   logit[t,q,k] = -1/2 sum_d ((w[t,k,d] - z[t,q,d])^2 * s[t,k,d]) + 1/2 sum_d log(s[t,k,d] + eps),
+// both sums in torch's last-dim order, the log being MKL's vsLn.  Blocking as k_kmeans_logits_rows.
+template <int E, int kRowsPerBlock>
+__global__ __launch_bounds__(256) void k_cov_logits_rows(const float* __restrict__ w, const float* __restrict__ s,
+                                                         const float* __restrict__ z, const uint8_t* __restrict__ need,
+                                                         int Q, int K, float* __restrict__ logit0) {
+    const int lane = threadIdx.x & (kGroup - 1);
+    const int group = threadIdx.x / kGroup, groups_per_block = blockDim.x / kGroup;
+    const int t = blockIdx.y, k0 = blockIdx.x * kRowsPerBlock;
+    bool want[kRowsPerBlock];
+    bool any = false;
+    float wv[kRowsPerBlock][E], sv[kRowsPerBlock][E], det[kRowsPerBlock];
+#pragma unroll
+    for (int j = 0; j < kRowsPerBlock; j++) {
+        want[j] = k0 + j < K && need[(size_t)t * K + k0 + j];
+        any = any || want[j];
+        float lg[E];
+#pragma unroll
+        for (int e = 0; e < E; e++) {
+            const int d = e * kGroup + lane;
+            const bool in = want[j] && d < K;
+            wv[j][e] = in ? w[((size_t)t * K + k0 + j) * K + d] : 0.0f;
+            sv[j][e] = in ? s[((size_t)t * K + k0 + j) * K + d] : 0.0f;
+            lg[e] = in ? log_f32(sv[j][e] + kEpsF) : 0.0f;
+        }
+        det[j] = 0.5f * group_sum_torch<E>(lg, K, lane);
+    }
+    if (!any) return;
+    for (int q = group; q < Q; q += groups_per_block) {
+        const float* zq = z + ((size_t)t * Q + q) * K;
+        float zv[E];
+#pragma unroll
+        for (int e = 0; e < E; e++) {
+            const int d = e * kGroup + lane;
+            zv[e] = d < K ? zq[d] : 0.0f;
+        }
+#pragma unroll
+        for (int j = 0; j < kRowsPerBlock; j++) {
+            if (!want[j]) continue;                                  // block-uniform
+            float pr[E];
+#pragma unroll
+            for (int e = 0; e < E; e++) {
+                const float df = e * kGroup + lane < K ? wv[j][e] - zv[e] : 0.0f;
+                pr[e] = (df * df) * sv[j][e];
+            }
+            const float ssum = group_sum_torch<E>(pr, K, lane);
+            if (lane == 0) logit0[((size_t)t * Q + q) * K + k0 + j] = -0.5f * ssum + det[j];
+        }
+    }
+}
+
 // E-step, part 3: u = softmax_k(logit0 + (lambd * v) / Q), torch CPU softmax order
 // (max, Sleef expf of the shifted row, 16-lane strided sum + butterfly, one reciprocal).
 // One 16-lane group per (task, query) row.  Also argmax (first maximum; pick_min: first minimum,
@@ -1423,6 +1500,14 @@ template <int E> struct LaunchKlDivergences {
         hipLaunchKernelGGL((k_kl_divergences<E, kRows>), dim3((K + kRows - 1) / kRows, T), dim3(256), 0, st, w, z, Q, K, divs);
     }
 };
+template <int E> struct LaunchCovLogitsRows {
+    static void run(int T, hipStream_t st, const float* w, const float* s, const float* z, const uint8_t* need, int Q, int K,
+                    float* logit0) {
+        constexpr int kRows = E <= 8 ? 4 : (E <= 16 ? 2 : 1);        // registers: 2 x kRows x E for centroids and covariances
+        hipLaunchKernelGGL((k_cov_logits_rows<E, kRows>), dim3((K + kRows - 1) / kRows, T), dim3(256), 0, st, w, s, z, need, Q, K,
+                           logit0);
+    }
+};
 template <int E> struct LaunchKmeansLogitsRows {
     static void run(int T, hipStream_t st, const float* w, const float* z, const uint8_t* need, int Q, int K, float pre,
                     float temperature, float* logit0) {
@@ -1434,17 +1519,28 @@ template <int E> struct LaunchKmeansLogitsRows {
 
 // M-step statistics / centroids / prototypes: rows whose K columns all lie in torch's cascade region
 // go through the 8-rows-per-thread kernel, the last few rows through the one-row kernel.
-static void launch_mstats(hipStream_t st, const float* u, const float* f, const float* cs, const uint8_t* live,
-                          const float* sup, const float* cnt, int T, int Q, int K, float* y, int paddle) {
+template <bool kCov>
+static void launch_mstats_mode(hipStream_t st, const float* u, const float* f, const float* cs, const uint8_t* live,
+                               const float* sup, const float* cnt, int T, int Q, int K, float* y, int paddle, const float* wc) {
     const long ncols = (long)K * K;
     const int full_rows = ncols >= 8 ? (int)(((ncols / 32) * 32) / K) : 0;      // rows 0 .. full_rows-1 are all-cascade
     const int groups = full_rows / kMstatsRows;
     if (groups > 0)
-        hipLaunchKernelGGL(k_mstats_rows, dim3((K + 63) / 64, groups, T), dim3(64), 0, st, u, f, cs, live, sup, cnt, Q, K, y, paddle);
+        hipLaunchKernelGGL(k_mstats_rows<kCov>, dim3((K + 63) / 64, groups, T), dim3(64), 0, st, u, f, cs, live, sup, cnt, Q, K, y,
+                           paddle, wc);
     const int k_first = groups * kMstatsRows;
     if (k_first < K)
-        hipLaunchKernelGGL(k_mstats, dim3((K + 63) / 64, K - k_first, T), dim3(64), 0, st, u, f, cs, live, sup, cnt, Q, K, y,
-                           paddle, k_first);
+        hipLaunchKernelGGL(k_mstats<kCov>, dim3((K + 63) / 64, K - k_first, T), dim3(64), 0, st, u, f, cs, live, sup, cnt, Q, K, y,
+                           paddle, k_first, wc);
+}
+static void launch_mstats(hipStream_t st, const float* u, const float* f, const float* cs, const uint8_t* live,
+                          const float* sup, const float* cnt, int T, int Q, int K, float* y, int paddle) {
+    launch_mstats_mode<false>(st, u, f, cs, live, sup, cnt, T, Q, K, y, paddle, nullptr);
+}
+// EM_GAUSSIAN_COV: s = cs / max(sum_q (w - z_q)^2 u, eps) for the rows `live` marks
+static void launch_cov_stats(hipStream_t st, const float* u, const float* z, const float* cs, const uint8_t* live,
+                             const float* w, int T, int Q, int K, float* s) {
+    launch_mstats_mode<true>(st, u, z, cs, live, nullptr, nullptr, T, Q, K, s, 0, w);
 }
 
 static int ew_grid(size_t n) {
@@ -1779,6 +1875,51 @@ int tclip_em_gaussian_run(const tclip_problem* pp, const float* x_q, float tempe
     if (int rc = check_problem(pp)) return rc;
     if (!v) return fail(TCLIP_ERR_ARG, "null pointer argument");
     return soft_kmeans_core(*pp, x_q, temperature, v, u, w, preds, workspace, workspace_bytes, stream, "EM_GAUSSIAN");
+}
+
+// ---- EM_GAUSSIAN_COV: EM_GAUSSIAN with a diagonal inverse covariance per cluster; no temperature
+int tclip_em_gaussian_cov_run(const tclip_problem* pp, const float* x_q, float* u, float* v, float* w, float* s,
+                              int32_t* preds, void* workspace, size_t workspace_bytes, void* stream) {
+    if (int rc = check_problem(pp)) return rc;
+    const tclip_problem p = *pp;
+    if (!x_q || !u || !v || !w || !s || !preds || !workspace) return fail(TCLIP_ERR_ARG, "null pointer argument");
+    if (p.n_support != 0) return fail(TCLIP_ERR_ARG, "EM_GAUSSIAN_COV is a zero-shot method: n_support must be 0");
+    size_t o_cs, o_live, o_ones, o_logit, o_rows, o_scratch, o_counts;
+    const size_t total = kmeans_ws_parts(p, &o_cs, &o_live, &o_ones, &o_logit, &o_rows, &o_scratch, &o_counts);
+    if (workspace_bytes < total) return fail(TCLIP_ERR_WORKSPACE, "workspace smaller than tclip_soft_kmeans_workspace_bytes()");
+    if (((uintptr_t)workspace & 255) != 0) return fail(TCLIP_ERR_WORKSPACE, "workspace must be 256-byte aligned");
+    hipStream_t st = (hipStream_t)stream;
+    char* ws = (char*)workspace;
+    const int Q = p.n_query, K = p.n_class, T = p.n_batches * p.tasks_per_batch, TK = T * K;
+    const size_t TQK = (size_t)T * Q * K;
+    float* cs = (float*)(ws + o_cs);
+    uint8_t* live = (uint8_t*)(ws + o_live);
+    uint8_t* ones = (uint8_t*)(ws + o_ones);
+    float* logit0 = (float*)(ws + o_logit);
+    hipLaunchKernelGGL(k_copy, dim3(ew_grid(TQK)), dim3(256), 0, st, x_q, u, TQK);          // u = z
+    TCLIP_HIP(hipMemsetAsync(ones, 1, (size_t)TK, st));
+    hipLaunchKernelGGL(k_fill, dim3(ew_grid(TK)), dim3(256), 0, st, v, 0.0f, (size_t)TK);
+    // w_init, s_init: every cluster                                                (em_gaussian_cov.py:146-180)
+    hipLaunchKernelGGL(k_cluster_sizes, dim3((TK + 255) / 256), dim3(256), 0, st, (const float*)u, T, Q, K, 1, cs, live,
+                       (float*)nullptr, (int32_t*)nullptr);
+    launch_mstats(st, (const float*)u, x_q, (const float*)cs, (const uint8_t*)ones, (const float*)nullptr, (const float*)nullptr, T, Q, K, w, 0);
+    launch_cov_stats(st, (const float*)u, x_q, (const float*)cs, (const uint8_t*)ones, (const float*)w, T, Q, K, s);
+    for (int it = 0; it < p.iters; it++) {
+        // w_update, s_update: non-empty clusters move, empty ones keep w and s        (:160-193); v of the previous v_update
+        hipLaunchKernelGGL(k_cluster_sizes, dim3((TK + 255) / 256), dim3(256), 0, st, (const float*)u, T, Q, K, 1, cs,
+                           live, it > 0 ? v : (float*)nullptr, (int32_t*)nullptr);
+        launch_mstats(st, (const float*)u, x_q, (const float*)cs, (const uint8_t*)live, (const float*)nullptr, (const float*)nullptr, T, Q, K, w, 0);
+        launch_cov_stats(st, (const float*)u, x_q, (const float*)cs, (const uint8_t*)live, (const float*)w, T, Q, K, s);
+        // u_update: Mahalanobis distances + log-determinants of the clusters that moved, softmax with lambd v / Q   (:106-129)
+        dispatch_E<LaunchCovLogitsRows>(K, T, st, (const float*)w, (const float*)s, x_q, (const uint8_t*)(it == 0 ? ones : live), Q, K,
+                                        logit0);
+        hipLaunchKernelGGL(k_softmax, dim3((T * Q * 16 + 255) / 256), dim3(256), 0, st, (const float*)logit0,
+                           (const float*)v, T * Q, Q, K, (float)p.lambd, 0, 0, u, preds);
+    }
+    hipLaunchKernelGGL(k_cluster_sizes, dim3((TK + 255) / 256), dim3(256), 0, st, (const float*)u, T, Q, K, 1, cs, live, v,
+                       (int32_t*)nullptr);                                              // the last v_update
+    TCLIP_HIP(hipGetLastError());
+    return TCLIP_OK;
 }
 
 size_t tclip_hard_kmeans_workspace_bytes(const tclip_problem* p) {

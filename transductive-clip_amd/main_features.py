@@ -38,6 +38,7 @@ METHOD_DEFAULTS = {
     "hard_kmeans": dict(name_method="HARD_KMEANS", iter=10, graph_matching=True, tunable=False),
     "kl_kmeans": dict(name_method="KL_KMEANS", iter=10, graph_matching=True, tunable=False),
     "em_gaussian": dict(name_method="EM_GAUSSIAN", iter=20, graph_matching=True, tunable=False),
+    "em_gaussian_cov": dict(name_method="EM_GAUSSIAN_COV", iter=20, graph_matching=True, tunable=False),
     "paddle": dict(name_method="PADDLE", iter=20, lambd=0.0, tunable=True),
 }
 

@@ -26,6 +26,7 @@ _SIGNATURES = {
     "tclip_soft_kmeans_workspace_bytes": (ctypes.c_size_t, [ctypes.POINTER(Problem)]),
     "tclip_soft_kmeans_run": (ctypes.c_int, [ctypes.POINTER(Problem), _P, ctypes.c_float, _P, _P, _P, _P, ctypes.c_size_t, _P]),
     "tclip_em_gaussian_run": (ctypes.c_int, [ctypes.POINTER(Problem), _P, ctypes.c_float, _P, _P, _P, _P, _P, ctypes.c_size_t, _P]),
+    "tclip_em_gaussian_cov_run": (ctypes.c_int, [ctypes.POINTER(Problem), _P, _P, _P, _P, _P, _P, _P, ctypes.c_size_t, _P]),
     "tclip_paddle_workspace_bytes": (ctypes.c_size_t, [ctypes.POINTER(Problem)]),
     "tclip_paddle_run": (ctypes.c_int, [ctypes.POINTER(Problem), _P, _P, _P, ctypes.c_float, _P, _P, _P, _P, _P, ctypes.c_size_t, _P]),
     "tclip_hard_kmeans_workspace_bytes": (ctypes.c_size_t, [ctypes.POINTER(Problem)]),

@@ -122,6 +122,33 @@ def run_em_gaussian(x_q, *, iters, temperature, lambd):
     return u, v, w, preds
 
 
+def run_em_gaussian_cov(x_q, *, iters, lambd):
+    """EM_GAUSSIAN_COV: x_q (T,Q,K) f32 cuda -> (u (T,Q,K), v (T,K), w (T,K,K), s (T,K,K), preds (T,Q) i32),
+    cuda, not synchronised."""
+    _require_cuda(x_q, "x_q")
+    x_q = x_q.contiguous().float()
+    T, Q, K = x_q.shape
+    dev = x_q.device
+    p = _capi.Problem(1, T, Q, K, 0, iters, 1, int(lambd), 0)
+    lib = _capi.lib()
+    ws_bytes = lib.tclip_soft_kmeans_workspace_bytes(ctypes.byref(p))
+    if ws_bytes == 0:
+        raise RuntimeError("tclip_soft_kmeans_workspace_bytes rejected the problem: " + lib.tclip_last_error().decode())
+    with torch.cuda.device(dev):
+        ws = torch.empty(ws_bytes + 256, dtype=torch.uint8, device=dev)
+        off = (-ws.data_ptr()) % 256
+        u = torch.empty(T, Q, K, device=dev)
+        v = torch.empty(T, K, device=dev)
+        w = torch.empty(T, K, K, device=dev)
+        s = torch.empty(T, K, K, device=dev)
+        preds = torch.empty(T, Q, dtype=torch.int32, device=dev)
+        rc = lib.tclip_em_gaussian_cov_run(ctypes.byref(p), _ptr(x_q), _ptr(u), _ptr(v), _ptr(w), _ptr(s), _ptr(preds),
+                                           ctypes.c_void_p(ws.data_ptr() + off), ws_bytes, _stream())
+        _capi.check(rc, "tclip_em_gaussian_cov_run")
+        ws.record_stream(torch.cuda.current_stream())
+    return u, v, w, s, preds
+
+
 def run_kl_kmeans(x_q, *, iters, n_batches=1):
     """KL_KMEANS: same outputs as run_hard_kmeans."""
     return run_hard_kmeans(x_q, iters=iters, n_batches=n_batches, _entry="tclip_kl_kmeans_run")
