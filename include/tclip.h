@@ -141,6 +141,20 @@ int tclip_hard_kmeans_run(const tclip_problem* p, const float* x_q, float* u, fl
 int tclip_kl_kmeans_run(const tclip_problem* p, const float* x_q, float* u, float* w, int32_t* preds,
                         float* criterions, void* workspace, size_t workspace_bytes, void* stream);
 
+/* BD-CSPN on probability features (reference: src/methods/few_shot/bdcspn.py:42-200; feature
+ * dimension = n_class).  One pass: feature normalisation (norm_type 0 = UN, 1 = L2N, 2 = CL2N with
+ * the support mean of the task), support class means, query shift eta = mean(support) - mean(query),
+ * soft assignment u' = softmax_k(temp * -1/2 ||w_k/|w_k| - a/|a|||^2) of the support + shifted
+ * queries a, rectified prototypes = u'-weighted means of the normalised a, prediction
+ * u = softmax_k(temp * -1/2 ||p_k/|p_k| - z_q/|z_q|||^2) (args.temp of bdcspn.yaml).
+ * Uses n_batches * tasks_per_batch tasks, n_query, n_class, n_support; iters is ignored.
+ *   x_q device [T,Q,K] f32;  x_s device [T,S,K] f32;  y_s device [T,S] i64;
+ *   prototypes device [T,K,K] out;  u device [T,Q,K] out;  preds device [T,Q] i32 out (argmax of u). */
+size_t tclip_bdcspn_workspace_bytes(const tclip_problem* p);
+int tclip_bdcspn_run(const tclip_problem* p, const float* x_q, const float* x_s, const int64_t* y_s, float temp,
+                     int32_t norm_type, float* prototypes, float* u, int32_t* preds, void* workspace,
+                     size_t workspace_bytes, void* stream);
+
 /* PADDLE on probability features (reference: src/methods/few_shot/paddle.py:94-219; feature
  * dimension = n_class).  Prototypes start as the class means of the support set; each iteration:
  * u = softmax_k(-1/2 ||w_k - z_q||^2 + lambd v_k / Q), v = log(mean_q u + eps) + 1,

@@ -279,6 +279,52 @@ def run_em_gaussian(x_q, *, n_class, iters, temperature, lambd):
             "seconds": time.time() - t0}
 
 
+def _bdcspn_logits(w, samples):
+    """BDCSPN.get_logits (few_shot/bdcspn.py:42-58): -1/2 squared distance of the L2-normalised arguments."""
+    w = w / w.norm(p=2, dim=-1, keepdim=True)
+    samples = samples / samples.norm(p=2, dim=-1, keepdim=True)
+    if len(w.shape) == 3:
+        diff = w.unsqueeze(1) - samples.unsqueeze(2)
+    else:
+        diff = w.unsqueeze(0) - samples.unsqueeze(1)
+    return -1 / 2 * (diff.square_()).sum(dim=-1)
+
+
+def run_bdcspn(x_q, x_s, y_s, *, n_class, temp, norm_type="L2N"):
+    """BD-CSPN on probability features, the reference's torch op sequence
+    (src/methods/few_shot/bdcspn.py:77-200): feature normalisation (CL2N / L2N / none), support
+    class means, per task a query shift eta = mean(support) - mean(query), soft assignment of
+    support + shifted queries to the means, rectified prototypes = assignment-weighted means of
+    the normalised augmented set, prediction = argmax softmax(temp * -1/2 ||.||^2) against them.
+    Returns dict(prototypes (N,K,C), u (N,Q,K), preds (N,Q), seconds)."""
+    support, query = x_s.clone().float(), x_q.clone().float()
+    y_s = y_s.long().view(support.shape[0], -1)
+    t0 = time.time()
+    train_mean = support.mean(1).unsqueeze(1)
+    if norm_type == "CL2N":
+        support = support - train_mean
+        support = support / support.norm(p=2, dim=2, keepdim=True)
+        query = query - train_mean
+        query = query / query.norm(p=2, dim=2, keepdim=True)
+    elif norm_type == "L2N":
+        support = support / support.norm(p=2, dim=2, keepdim=True)
+        query = query / query.norm(p=2, dim=2, keepdim=True)
+    n_task, n_query, dim = query.shape
+    prototypes = torch.zeros(n_task, n_class, dim)
+    ys_hot = one_hot_rows(y_s, n_class)
+    counts = ys_hot.sum(1).unsqueeze(-1)
+    init = (ys_hot.unsqueeze(-1) * support.unsqueeze(2)).sum(1).div_(counts)
+    for j in range(n_task):
+        eta = support[j].mean(0) - query[j].mean(0)
+        aug = torch.cat((support[j], query[j] + eta), dim=0)
+        u = (temp * _bdcspn_logits(init[j], aug)).softmax(-1)
+        aug = aug / aug.norm(p=2, dim=-1, keepdim=True)
+        cnt = u.sum(0).unsqueeze(-1)
+        prototypes[j] = (u.unsqueeze(-1) * aug.unsqueeze(1)).sum(0).div_(cnt)
+    u = (temp * _bdcspn_logits(prototypes, query)).softmax(-1)
+    return {"prototypes": prototypes, "u": u, "preds": u.argmax(2), "seconds": time.time() - t0}
+
+
 def run_em_gaussian_cov(x_q, *, n_class, iters, lambd):
     """EM_GAUSSIAN_COV on probability features, the reference's torch op sequence
     (src/methods/zero_shot/em_gaussian_cov.py:106-257): EM_GAUSSIAN with a diagonal inverse

@@ -33,6 +33,8 @@ for c in cases(d["n_cases"], d["seed"]):
          "cov": ref_torch.run_em_gaussian_cov(x_q, n_class=K, iters=c["iters"], lambd=lam),
          "klk": ref_torch.run_kl_kmeans(x_q, n_class=K, iters=c["iters"]),
          "paddle": ref_torch.run_paddle(x_q, x_s, y_s, n_class=K, iters=c["iters"], lambd=c["paddle_lambd"])}
+    if "bdcspn" in got:
+        t["bdcspn"] = ref_torch.run_bdcspn(x_q, x_s, y_s, n_class=K, temp=30.0, norm_type=("UN", "L2N", "CL2N")[c["case"] % 3])
     res = {m: all(digest(t[m][a]) == h for a, h in got[m].items()) for m in got}
     ok = all(res.values())
     bad += not ok

@@ -33,6 +33,9 @@ for c in cases(n_cases, seed):
     r["klk"] = {"u": digest(u), "w": digest(w)}
     u, v, w, p = engine.run_paddle(xc, x_s.cuda(), y_s.squeeze(2).cuda(), iters=c["iters"], lambd=c["paddle_lambd"])
     r["paddle"] = {"u": digest(u), "v": digest(v), "w": digest(w)}
+    nt = ("UN", "L2N", "CL2N")[c["case"] % 3]
+    pr, u, p = engine.run_bdcspn(xc, x_s.cuda(), y_s.squeeze(2).cuda(), temp=30.0, norm_type=nt)
+    r["bdcspn"] = {"prototypes": digest(pr), "u": digest(u)}
     out[str(c["case"])] = r
 os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
 path = os.path.join(ROOT, "gpurun_out", f"kmeans_dump_{seed}.json")

@@ -101,6 +101,10 @@ SMALL = {
     "fs_paddle_K5_N3_s2": ("fs_paddle", 5, 3, 20, 2, 2039, True),
     "zs_klk_K2_N4": ("zs_klk", 2, 4, 10, 0, 2040, True),
     "zs_klk_K7_N4": ("zs_klk", 7, 4, 10, 0, 2041, True),
+    # one iteration: the centroids of the SOFT initial assignment (products are inexact, unlike those of one-hot u);
+    # at K = 2 ATen's bmm is its own unfused triple loop (75 * 2 * 2 < 400), at K = 3 it is MKL's fused chain
+    "zs_klk_K2_N3_i1": ("zs_klk", 2, 3, 1, 0, 2042, True),
+    "zs_klk_K3_N2_i1": ("zs_klk", 3, 2, 1, 0, 2043, True),
     "zs_klk_K10_N4": ("zs_klk", 10, 4, 10, 0, 2020, True),
     "zs_klk_K37_N6": ("zs_klk", 37, 6, 10, 0, 2021, True),
     "zs_klk_K100_N4": ("zs_klk", 100, 4, 10, 0, 2022, True),

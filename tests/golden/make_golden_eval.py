@@ -63,7 +63,7 @@ def main():
     seed = 2020
     only = set(sys.argv[1:])
     cases = [("zs", False, None), ("zs", True, None), ("fs", False, None),
-             ("zs", False, "HARD_KMEANS"), ("zs", False, "EM_GAUSSIAN"), ("zs", False, "EM_GAUSSIAN_COV"), ("zs", False, "SOFT_KMEANS"), ("zs", False, "KL_KMEANS"), ("fs", False, "PADDLE")]
+             ("zs", False, "HARD_KMEANS"), ("zs", False, "EM_GAUSSIAN"), ("zs", False, "EM_GAUSSIAN_COV"), ("zs", False, "SOFT_KMEANS"), ("zs", False, "KL_KMEANS"), ("fs", False, "PADDLE"), ("fs", False, "BDCSPN")]
     for kind, hard, other in cases:
         K = 10
         method = other or ("HARD_EM_DIRICHLET" if hard else "EM_DIRICHLET")
@@ -72,7 +72,7 @@ def main():
         args = Args(iter=10 if (hard or other in ("HARD_KMEANS", "KL_KMEANS")) else 20, iter_mm=1000, num_classes_test=K, n_class=K,
                     n_query=75, k_eff=5, T=30, use_softmax_feature=True, graph_matching=True, shots=2, number_tasks=20,
                     batch_size=10, name_method=method, used_test_set="test", tunable=False, lambd=5.0,
-                    method=method.lower(), dataset="synthetic")
+                    method=method.lower(), dataset="synthetic", norm_type="L2N", temp=30.0, num_NN=1)
         feats, labels = synth.make_feature_table(K, 40, seed=seed)
         out = {"kind": kind, "hard": hard, "K": K, "seed": seed, "rows_per_class": 40, "method": method,
                "iters": args.iter, "lambd": args.lambd,

@@ -191,7 +191,7 @@ def test_full_size_properties_k100_batch100():
 
 @pytest.mark.parametrize("name", ["eval_zs_soft_K10", "eval_zs_hard_K10", "eval_fs_soft_K10", "eval_zs_soft_kmeans_K10",
                                   "eval_zs_hard_kmeans_K10", "eval_zs_em_gaussian_K10", "eval_zs_em_gaussian_cov_K10", "eval_zs_kl_kmeans_K10",
-                                  "eval_fs_paddle_K10"])
+                                  "eval_fs_paddle_K10", "eval_fs_bdcspn_K10"])
 def test_task_batch_loop_matches_reference(name):
     """evaluate_tasks on the seeded synthetic table: the reference's mean accuracy (fixtures made
     by running the reference's Evaluator_*.evaluate_tasks), for every method behind the boundary."""
@@ -204,7 +204,7 @@ def test_task_batch_loop_matches_reference(name):
     a = CfgNode(iter=iters, iter_mm=1000, num_classes_test=K, n_class=K, n_query=75, k_eff=5, T=30,
                 use_softmax_feature=True, graph_matching=True, shots=int(g["shots"]), number_tasks=int(g["number_tasks"]),
                 batch_size=int(g["batch_size"]), name_method=method, used_test_set="test",
-                lambd=float(g["lambd"]) if "lambd" in g.files else 0.0)
+                lambd=float(g["lambd"]) if "lambd" in g.files else 0.0, norm_type="L2N", temp=30.0)     # bdcspn.yaml defaults
     feats, labels = synth.make_feature_table(K, int(g["rows_per_class"]), seed=int(g["seed"]))
     random.seed(int(g["seed"]))
     torch.manual_seed(int(g["seed"]))

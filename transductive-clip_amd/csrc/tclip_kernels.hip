@@ -218,6 +218,8 @@ __global__ void k_mstats(const float* __restrict__ u, const float* __restrict__ 
     const float c = cs[row];
     if (kCov) {
         y[row * K + d] = c / (s < kEpsF ? kEpsF : s);
+    } else if (paddle == 2) {      // BD-CSPN rectified prototypes (few_shot/bdcspn.py:139-141): plain quotient
+        y[row * K + d] = s / c;
     } else if (sup && paddle) {           // PADDLE centroid (few_shot/paddle.py:154-158): (sum_q u z + support sum) / (sum_q u + count)
         y[row * K + d] = (s + sup[row * K + d]) / (c + cnt[row]);
     } else if (sup) {
@@ -290,6 +292,8 @@ __global__ __launch_bounds__(64) void k_mstats_rows(const float* __restrict__ u,
         const float c = cs[row];
         if (kCov) {
             y[row * K + d] = c / (s < kEpsF ? kEpsF : s);
+        } else if (paddle == 2) {
+            y[row * K + d] = s / c;
         } else if (sup && paddle) {
             y[row * K + d] = (s + sup[row * K + d]) / (c + cnt[row]);
         } else if (sup) {
@@ -1073,10 +1077,96 @@ __global__ void k_div_rows(const float* __restrict__ num, const float* __restric
         out[i] = num[i] / den[i / K];
 }
 
+// ---- BD-CSPN (few_shot/bdcspn.py)
+// torch's x.norm(p=2, dim=-1) on the AVX-512 host (probed bit for bit, 12 900 rows of width 1..1000):
+// eight accumulators, element d goes to accumulator d mod 8 with one fused multiply-add, for the
+// d < 8*floor(K/8); the accumulators are added in order 0..7; the remaining K mod 8 elements
+// follow, the first four of them (if there are that many) as rounded product + add, the rest
+// fused; one correctly rounded square root.  Eight consecutive lanes (j = 0..7) share a row;
+// `get(d)` yields element d.  The result is valid in all eight lanes.
+template <typename F>
+__device__ __forceinline__ float row_norm_torch(int K, int j, F get) {
+    const int nv = K & ~7;
+    float acc = 0.0f;
+    for (int d = j; d < nv; d += 8) {
+        const float v = get(d);
+        acc = __builtin_fmaf(v, v, acc);
+    }
+    float b = __shfl(acc, 0, 8);
+#pragma unroll
+    for (int l = 1; l < 8; l++) b += __shfl(acc, l, 8);
+    int d = nv;
+    if (K - d >= 4) {
+        for (int k = 0; k < 4; k++, d++) {
+            const float v = get(d);
+            b = b + v * v;
+        }
+    }
+    for (; d < K; d++) {
+        const float v = get(d);
+        b = __builtin_fmaf(v, v, b);
+    }
+    return __builtin_sqrtf(b);
+}
+
+// out[t,c] = mean_r x[t,r,c] = (torch outer sum over the R rows) / R      (bdcspn.py:165 train_mean, :127 eta)
+__global__ void k_col_mean(const float* __restrict__ x, int T, int R, int K, float* __restrict__ out) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= (size_t)T * K) return;
+    const int t = i / K, c = i % K;
+    const float* xt = x + (size_t)t * R * K;
+    out[i] = dsum_outer(R, c, K, [&](int r) { return xt[(size_t)r * K + c]; }) / (float)R;
+}
+
+// Feature normalisation (bdcspn.py:77-100) and get_logits' own (:50-51), eight lanes per row:
+//   mode 0 (UN) copy; 1 (L2N) x / ||x||; 2 (CL2N) (x - mean_t) / ||x - mean_t||.
+// With `shift` (rows >= shift_from of every task get + shift[t,:] first; the augmented set of
+// proto_rectification, :128-131) the source rows come from two arrays: rows < R0 from x, the rest from x2.
+__global__ __launch_bounds__(256) void k_bdcspn_normalize(const float* __restrict__ x, const float* __restrict__ x2, int R0,
+                                                          int R, int K, int mode, const float* __restrict__ mean,
+                                                          const float* __restrict__ shift, int n_rows,
+                                                          float* __restrict__ out) {
+    const int j = threadIdx.x & 7;
+    const int row = (blockIdx.x * blockDim.x + threadIdx.x) >> 3;
+    if (row >= n_rows) return;
+    const int t = row / R, r = row % R;
+    const float* src = r < R0 ? x + ((size_t)t * R0 + r) * K : x2 + ((size_t)t * (R - R0) + (r - R0)) * K;
+    const float* mt = mean ? mean + (size_t)t * K : nullptr;
+    const float* sh = (shift && r >= R0) ? shift + (size_t)t * K : nullptr;
+    auto get = [&](int d) {
+        float v = src[d];
+        if (sh) v = v + sh[d];
+        if (mode == 2) v = v - mt[d];
+        return v;
+    };
+    float* o = out + (size_t)row * K;
+    if (mode == 0) {
+        for (int d = j; d < K; d += 8) o[d] = get(d);
+        return;
+    }
+    const float nrm = row_norm_torch(K, j, get);
+    for (int d = j; d < K; d += 8) o[d] = get(d) / nrm;
+}
+
+// eta[t,c] = mean_s zs[t,s,c] - mean_q zq[t,q,c]                                              (bdcspn.py:127)
+__global__ void k_bdcspn_eta(const float* __restrict__ zs, const float* __restrict__ zq, int T, int S, int Q, int K,
+                             float* __restrict__ eta) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= (size_t)T * K) return;
+    const int t = i / K, c = i % K;
+    const float* a = zs + (size_t)t * S * K;
+    const float* b = zq + (size_t)t * Q * K;
+    const float ms = dsum_outer(S, c, K, [&](int r) { return a[(size_t)r * K + c]; }) / (float)S;
+    const float mq = dsum_outer(Q, c, K, [&](int r) { return b[(size_t)r * K + c]; }) / (float)Q;
+    eta[i] = ms - mq;
+}
+
 // KL_KMEANS (kl_kmeans.py:123-189).  Centroids: w = (u^T z) / max(sum_q u, 1), zero for empty clusters.
 // torch's bmm is MKL sgemm, which for these shapes accumulates every output as one chain of fused
 // multiply-adds over the queries in ascending order (probed against torch on soft and one-hot u:
 // identical on every entry), so a thread keeps kMstatsRows such chains for its feature column.
+// Below 400 multiply-adds per matrix (Q * K * K < 400, i.e. K = 2 at 75 queries) ATen does not call MKL but
+// its own triple loop (baddbmm_cpu_kernel), whose accumulation is a rounded product plus an add.
 __global__ __launch_bounds__(64) void k_kl_centroids(const float* __restrict__ u, const float* __restrict__ z,
                                                      const float* __restrict__ cs, int Q, int K, float* __restrict__ w) {
     const int t = blockIdx.z, k0 = blockIdx.y * kMstatsRows;
@@ -1087,12 +1177,14 @@ __global__ __launch_bounds__(64) void k_kl_centroids(const float* __restrict__ u
     float acc[kMstatsRows];
 #pragma unroll
     for (int j = 0; j < kMstatsRows; j++) acc[j] = 0.0f;
+    const bool fused = (long)Q * K * K >= 400;
     for (int q = 0; q < Q; q++) {
         const float zv = zt[(size_t)q * K];
 #pragma unroll
         for (int j = 0; j < kMstatsRows; j++) {
             const int k = k0 + j < K ? k0 + j : K - 1;
-            acc[j] = __builtin_fmaf(ut[(size_t)q * K + k], zv, acc[j]);
+            const float uv = ut[(size_t)q * K + k];
+            acc[j] = fused ? __builtin_fmaf(uv, zv, acc[j]) : acc[j] + uv * zv;
         }
     }
 #pragma unroll
@@ -2025,6 +2117,98 @@ int tclip_paddle_run(const tclip_problem* pp, const float* x_q, const float* x_s
                            v, (int32_t*)nullptr);
         launch_mstats(st, (const float*)u, (const float*)x_q, (const float*)cs, (const uint8_t*)live, (const float*)sup, (const float*)cnt, T, Q, K, w, 1);
     }
+    TCLIP_HIP(hipGetLastError());
+    return TCLIP_OK;
+}
+
+// ---- BD-CSPN: one pass, no loop
+struct BdcspnWs { size_t zs, zq, zqn, mean, eta, sup, cnt, wn, aug, logit, cs, live, dummy, total; };
+static BdcspnWs bdcspn_ws(const tclip_problem& p) {
+    const size_t T = (size_t)p.n_batches * p.tasks_per_batch, K = p.n_class, Q = p.n_query, S = p.n_support, R = S + Q;
+    BdcspnWs w;
+    size_t o = 0;
+    auto take = [&](size_t bytes) { size_t r = o; o += align_up(bytes); return r; };
+    w.zs = take(T * S * K * 4);
+    w.zq = take(T * Q * K * 4);
+    w.zqn = take(T * Q * K * 4);
+    w.mean = take(T * K * 4);
+    w.eta = take(T * K * 4);
+    w.sup = take(T * K * K * 4);
+    w.cnt = take(T * K * 4);
+    w.wn = take(T * K * K * 4);
+    w.aug = take(T * R * K * 4);
+    w.logit = take(T * R * K * 4);
+    w.cs = take(T * K * 4);
+    w.live = take(T * K);
+    w.dummy = take(T * R * 4);
+    w.total = o;
+    return w;
+}
+
+size_t tclip_bdcspn_workspace_bytes(const tclip_problem* p) {
+    if (check_problem(p) != TCLIP_OK) return 0;
+    return bdcspn_ws(*p).total;
+}
+
+int tclip_bdcspn_run(const tclip_problem* pp, const float* x_q, const float* x_s, const int64_t* y_s, float temp,
+                     int32_t norm_type, float* prototypes, float* u, int32_t* preds, void* workspace,
+                     size_t workspace_bytes, void* stream) {
+    if (int rc = check_problem(pp)) return rc;
+    const tclip_problem p = *pp;
+    if (!x_q || !x_s || !y_s || !prototypes || !u || !preds || !workspace) return fail(TCLIP_ERR_ARG, "null pointer argument");
+    if (p.n_support < 1) return fail(TCLIP_ERR_ARG, "BDCSPN is a few-shot method: n_support must be positive");
+    if (norm_type < 0 || norm_type > 2) return fail(TCLIP_ERR_ARG, "norm_type must be 0 (UN), 1 (L2N) or 2 (CL2N)");
+    const BdcspnWs o = bdcspn_ws(p);
+    if (workspace_bytes < o.total) return fail(TCLIP_ERR_WORKSPACE, "workspace smaller than tclip_bdcspn_workspace_bytes()");
+    if (((uintptr_t)workspace & 255) != 0) return fail(TCLIP_ERR_WORKSPACE, "workspace must be 256-byte aligned");
+    hipStream_t st = (hipStream_t)stream;
+    char* ws = (char*)workspace;
+    const int Q = p.n_query, K = p.n_class, S = p.n_support, R = S + Q, T = p.n_batches * p.tasks_per_batch, TK = T * K;
+    float* zs = (float*)(ws + o.zs);
+    float* zq = (float*)(ws + o.zq);
+    float* zqn = (float*)(ws + o.zqn);
+    float* mean = (float*)(ws + o.mean);
+    float* eta = (float*)(ws + o.eta);
+    float* sup = (float*)(ws + o.sup);
+    float* cnt = (float*)(ws + o.cnt);
+    float* wn = (float*)(ws + o.wn);
+    float* aug = (float*)(ws + o.aug);
+    float* logit = (float*)(ws + o.logit);
+    float* cs = (float*)(ws + o.cs);
+    uint8_t* live = (uint8_t*)(ws + o.live);
+    int32_t* dummy = (int32_t*)(ws + o.dummy);
+    auto rows_grid = [](int n_rows) { return dim3((unsigned)(((size_t)n_rows * 8 + 255) / 256)); };
+    auto normalize = [&](const float* x, const float* x2, int R0, int Rr, int mode, const float* mn, const float* sh, float* out) {
+        hipLaunchKernelGGL(k_bdcspn_normalize, rows_grid(T * Rr), dim3(256), 0, st, x, x2, R0, Rr, K, mode, mn, sh, T * Rr, out);
+    };
+    // normalization (bdcspn.py:77-100, :165-166): train_mean = support.mean(1); CL2N / L2N / none
+    if (norm_type == 2) hipLaunchKernelGGL(k_col_mean, dim3((TK + 255) / 256), dim3(256), 0, st, x_s, T, S, K, mean);
+    normalize(x_s, x_s, S, S, norm_type, (const float*)mean, (const float*)nullptr, zs);
+    normalize(x_q, x_q, Q, Q, norm_type, (const float*)mean, (const float*)nullptr, zq);
+    // initial prototypes: support class means (:117-120), L2-normalised for get_logits (:50)
+    hipLaunchKernelGGL(k_support_stats, dim3(K, T), dim3(128), (size_t)S * sizeof(int), st, (const float*)zs, y_s, S, K, 0, sup, cnt);
+    hipLaunchKernelGGL(k_div_rows, dim3(ew_grid((size_t)TK * K)), dim3(256), 0, st, (const float*)sup, (const float*)cnt,
+                       (size_t)TK * K, K, prototypes);
+    normalize((const float*)prototypes, (const float*)prototypes, K, K, 1, (const float*)nullptr, (const float*)nullptr, wn);
+    // augmented set: support rows, then query rows shifted by eta = mean(support) - mean(query); normalised (:127-131, :51, :137)
+    hipLaunchKernelGGL(k_bdcspn_eta, dim3((TK + 255) / 256), dim3(256), 0, st, (const float*)zs, (const float*)zq, T, S, Q, K, eta);
+    normalize((const float*)zs, (const float*)zq, S, R, 1, (const float*)nullptr, (const float*)eta, aug);
+    // soft assignment of the augmented set to the initial prototypes (:133-134)
+    TCLIP_HIP(hipMemsetAsync(live, 1, (size_t)TK, st));
+    dispatch_E<LaunchKmeansLogitsRows>(K, T, st, (const float*)wn, (const float*)aug, (const uint8_t*)live, R, K, -0.5f, temp, logit);
+    hipLaunchKernelGGL(k_softmax, dim3((T * R * 16 + 255) / 256), dim3(256), 0, st, (const float*)logit, (const float*)nullptr,
+                       T * R, R, K, 0.0f, 0, 0, logit, dummy);
+    // rectified prototypes = assignment-weighted means of the normalised augmented set (:137-141)
+    hipLaunchKernelGGL(k_cluster_sizes, dim3((TK + 255) / 256), dim3(256), 0, st, (const float*)logit, T, R, K, 0, cs, live,
+                       (float*)nullptr, (int32_t*)nullptr);
+    launch_mstats(st, (const float*)logit, (const float*)aug, (const float*)cs, (const uint8_t*)live, (const float*)nullptr,
+                  (const float*)nullptr, T, R, K, prototypes, 2);
+    // prediction (:190-193): softmax(temp * get_logits(prototypes, query)), argmax
+    normalize((const float*)prototypes, (const float*)prototypes, K, K, 1, (const float*)nullptr, (const float*)nullptr, wn);
+    normalize((const float*)zq, (const float*)zq, Q, Q, 1, (const float*)nullptr, (const float*)nullptr, zqn);
+    dispatch_E<LaunchKmeansLogitsRows>(K, T, st, (const float*)wn, (const float*)zqn, (const uint8_t*)live, Q, K, -0.5f, temp, logit);
+    hipLaunchKernelGGL(k_softmax, dim3((T * Q * 16 + 255) / 256), dim3(256), 0, st, (const float*)logit, (const float*)nullptr,
+                       T * Q, Q, K, 0.0f, 0, 0, u, preds);
     TCLIP_HIP(hipGetLastError());
     return TCLIP_OK;
 }

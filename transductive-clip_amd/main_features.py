@@ -40,6 +40,7 @@ METHOD_DEFAULTS = {
     "em_gaussian": dict(name_method="EM_GAUSSIAN", iter=20, graph_matching=True, tunable=False),
     "em_gaussian_cov": dict(name_method="EM_GAUSSIAN_COV", iter=20, graph_matching=True, tunable=False),
     "paddle": dict(name_method="PADDLE", iter=20, lambd=0.0, tunable=True),
+    "bdcspn": dict(name_method="BDCSPN", num_NN=1, norm_type="L2N", temp=30.0, tunable=True),
 }
 
 

@@ -8,12 +8,13 @@ import torch
 from src.methods.few_shot.em_dirichlet import EM_DIRICHLET
 from src.methods.few_shot.hard_em_dirichlet import HARD_EM_DIRICHLET
 from src.methods.few_shot.paddle import PADDLE
+from src.methods.few_shot.bdcspn import BDCSPN
 from src.sampler_few_shot import CategoriesSampler_few_shot, SamplerQuery_few_shot, SamplerSupport_few_shot
 from src.task_generator_few_shot import relabel
 from src.utils import Logger, compute_confidence_interval
 from tclip_amd import engine, sharding
 
-_METHODS = {'EM_DIRICHLET': EM_DIRICHLET, 'HARD_EM_DIRICHLET': HARD_EM_DIRICHLET, 'PADDLE': PADDLE}
+_METHODS = {'EM_DIRICHLET': EM_DIRICHLET, 'HARD_EM_DIRICHLET': HARD_EM_DIRICHLET, 'PADDLE': PADDLE, 'BDCSPN': BDCSPN}
 
 
 class Evaluator_few_shot:
@@ -74,7 +75,9 @@ class Evaluator_few_shot:
         x_s, x_q = torch.stack(xs2, 0), torch.stack(xq2, 0)
         y_s, y_q = torch.stack(ys2, 0), torch.stack(yq2, 0)
         method = self.get_method_builder(model=model, device=self.device, args=a, log_file=self.log_file)
-        method.run_method(support=x_s, query=x_q, y_s=y_s.to(dev), y_q=y_q.to(dev), n_batches=len(mine))
+        # BDCSPN normalises the features in run_task, before run_method (few_shot/bdcspn.py:165-166): run_batch does both
+        run = getattr(method, "run_batch", method.run_method)
+        run(support=x_s, query=x_q, y_s=y_s.to(dev), y_q=y_q.to(dev), n_batches=len(mine))
         logs = method.get_logs()
         acc = torch.from_numpy(logs['acc'][:, -1].copy()).view(len(mine), N).to(dev)
         acc = sharding.gather_batch_results(acc, n_batches)

@@ -29,6 +29,8 @@ _SIGNATURES = {
     "tclip_em_gaussian_cov_run": (ctypes.c_int, [ctypes.POINTER(Problem), _P, _P, _P, _P, _P, _P, _P, ctypes.c_size_t, _P]),
     "tclip_paddle_workspace_bytes": (ctypes.c_size_t, [ctypes.POINTER(Problem)]),
     "tclip_paddle_run": (ctypes.c_int, [ctypes.POINTER(Problem), _P, _P, _P, ctypes.c_float, _P, _P, _P, _P, _P, ctypes.c_size_t, _P]),
+    "tclip_bdcspn_workspace_bytes": (ctypes.c_size_t, [ctypes.POINTER(Problem)]),
+    "tclip_bdcspn_run": (ctypes.c_int, [ctypes.POINTER(Problem), _P, _P, _P, ctypes.c_float, ctypes.c_int32, _P, _P, _P, _P, ctypes.c_size_t, _P]),
     "tclip_hard_kmeans_workspace_bytes": (ctypes.c_size_t, [ctypes.POINTER(Problem)]),
     "tclip_hard_kmeans_run": (ctypes.c_int, [ctypes.POINTER(Problem), _P, _P, _P, _P, _P, _P, ctypes.c_size_t, _P]),
     "tclip_kl_kmeans_run": (ctypes.c_int, [ctypes.POINTER(Problem), _P, _P, _P, _P, _P, _P, ctypes.c_size_t, _P]),

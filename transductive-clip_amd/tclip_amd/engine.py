@@ -215,6 +215,43 @@ def run_paddle(x_q, x_s, y_s, *, iters, lambd):
     return u, v, w, preds
 
 
+NORM_TYPES = {"UN": 0, "L2N": 1, "CL2N": 2}
+
+
+def run_bdcspn(x_q, x_s, y_s, *, temp, norm_type="L2N"):
+    """BD-CSPN: x_q (T,Q,K), x_s (T,S,K) f32 cuda, y_s (T,S) int64 cuda ->
+    (prototypes (T,K,K), u (T,Q,K), preds (T,Q) i32), cuda, not synchronised."""
+    _require_cuda(x_q, "x_q")
+    _require_cuda(x_s, "x_s")
+    _require_cuda(y_s, "y_s")
+    if norm_type not in NORM_TYPES:
+        raise ValueError(f"norm_type must be one of {sorted(NORM_TYPES)}")
+    x_q, x_s = x_q.contiguous().float(), x_s.contiguous().float()
+    y_s = y_s.reshape(x_s.shape[0], -1).contiguous().long()
+    T, Q, K = x_q.shape
+    S = x_s.shape[1]
+    if x_s.shape != (T, S, K) or y_s.shape != (T, S):
+        raise ValueError("x_s must be (T,S,K) and y_s (T,S) with the T and K of x_q")
+    dev = x_q.device
+    p = _capi.Problem(1, T, Q, K, S, 1, 1, 0, 0)
+    lib = _capi.lib()
+    ws_bytes = lib.tclip_bdcspn_workspace_bytes(ctypes.byref(p))
+    if ws_bytes == 0:
+        raise RuntimeError("tclip_bdcspn_workspace_bytes rejected the problem: " + lib.tclip_last_error().decode())
+    with torch.cuda.device(dev):
+        ws = torch.empty(ws_bytes + 256, dtype=torch.uint8, device=dev)
+        off = (-ws.data_ptr()) % 256
+        prototypes = torch.empty(T, K, K, device=dev)
+        u = torch.empty(T, Q, K, device=dev)
+        preds = torch.empty(T, Q, dtype=torch.int32, device=dev)
+        rc = lib.tclip_bdcspn_run(ctypes.byref(p), _ptr(x_q), _ptr(x_s), _ptr(y_s), ctypes.c_float(float(temp)),
+                                  ctypes.c_int32(NORM_TYPES[norm_type]), _ptr(prototypes), _ptr(u), _ptr(preds),
+                                  ctypes.c_void_p(ws.data_ptr() + off), ws_bytes, _stream())
+        _capi.check(rc, "tclip_bdcspn_run")
+        ws.record_stream(torch.cuda.current_stream())
+    return prototypes, u, preds
+
+
 def clustering_accuracy(x_q, preds, y_q, graph_matching=True):
     """Zero-shot accuracy tail: device prototypes of the predicted clusters, host assignment.
 
