@@ -52,3 +52,16 @@ x, xs, ys = x.cuda(), xs.cuda(), ys.squeeze(2).cuda()
 timed_fn("PADDLE K=100 4-shot, 1000 tasks, 20 iterations",
          lambda: engine.run_paddle(x, xs, ys, iters=20, lambd=5.0),
          lambda dt: f"{T / dt:.0f} tasks/s")
+T, K = 1000, 397
+x, _ = synth.make_query_tasks(T, K, seed=6); x = x.cuda()
+timed_fn("EM_GAUSSIAN K=397, 1000 tasks, 20 iterations",
+         lambda: engine.run_em_gaussian(x, iters=20, temperature=30, lambd=79 * 75), lambda dt: f"{T / dt:.0f} tasks/s")
+timed_fn("EM_GAUSSIAN_COV K=397, 1000 tasks, 20 iterations",
+         lambda: engine.run_em_gaussian_cov(x, iters=20, lambd=79 * 75), lambda dt: f"{T / dt:.0f} tasks/s")
+timed_fn("KL_KMEANS K=397, 1000 tasks, 10 iterations",
+         lambda: engine.run_kl_kmeans(x, iters=10, n_batches=10), lambda dt: f"{T / dt:.0f} tasks/s")
+T, K = 1000, 100
+x, _ = synth.make_query_tasks(T, K, seed=6, k_eff=5); xs, ys = synth.make_support(T, K, 4, seed=6)
+x, xs, ys = x.cuda(), xs.cuda(), ys.squeeze(2).cuda()
+timed_fn("BDCSPN K=100 4-shot, 1000 tasks (L2N)",
+         lambda: engine.run_bdcspn(x, xs, ys, temp=30.0, norm_type="L2N"), lambda dt: f"{T / dt:.0f} tasks/s")

@@ -1213,20 +1213,42 @@ __global__ __launch_bounds__(256) void k_kl_divergences(const float* __restrict_
             qv[j][e] = (k0 + j < K && d < K) ? w[((size_t)t * K + k0 + j) * K + d] + kEpsF : 1.0f;
         }
     }
+    __shared__ uint32_t s_buckets[64];
+    __shared__ float s_t1[32], s_t2[32];
+    if (threadIdx.x < 64) s_buckets[threadIdx.x] = kRcp14Buckets.e[threadIdx.x];
+    if (threadIdx.x < 32) { s_t1[threadIdx.x] = kSlnT1[threadIdx.x]; s_t2[threadIdx.x] = kSlnT2[threadIdx.x]; }
+    __syncthreads();
+    // probability features keep P, Q and P / Q inside the range of the short exact quotient and of the
+    // restated MKL log's main path; anything else (checked per wave) takes the IEEE operator and log_f32
+    bool q_in = true;
+#pragma unroll
+    for (int j = 0; j < kRowsPerBlock; j++)
+#pragma unroll
+        for (int e = 0; e < E; e++) q_in = q_in && fast_range_f32(qv[j][e]);
+    const bool q_ok = __all(q_in);
     for (int q = group; q < Q; q += groups_per_block) {
         const float* zq = z + ((size_t)t * Q + q) * K;
         float pv[E];
+        bool p_in = true;
 #pragma unroll
         for (int e = 0; e < E; e++) {
             const int d = e * kGroup + lane;
             pv[e] = d < K ? zq[d] + kEpsF : 1.0f;
+            p_in = p_in && fast_range_f32(pv[e]);
         }
+        const bool fast = q_ok && __all(p_in);                       // wave-uniform
 #pragma unroll
         for (int j = 0; j < kRowsPerBlock; j++) {
             if (k0 + j >= K) break;                                  // block-uniform
             float pr[E];
+            if (fast) {
 #pragma unroll
-            for (int e = 0; e < E; e++) pr[e] = e * kGroup + lane < K ? pv[e] * log_f32(pv[e] / qv[j][e]) : 0.0f;
+                for (int e = 0; e < E; e++)
+                    pr[e] = e * kGroup + lane < K ? pv[e] * log_mkl_inrange_tab(div_rn_inrange_f32(pv[e], qv[j][e]), s_buckets, s_t1, s_t2) : 0.0f;
+            } else {
+#pragma unroll
+                for (int e = 0; e < E; e++) pr[e] = e * kGroup + lane < K ? pv[e] * log_f32(pv[e] / qv[j][e]) : 0.0f;
+            }
             const float ssum = group_sum_torch<E>(pr, K, lane);
             if (lane == 0) divs[((size_t)t * Q + q) * K + k0 + j] = ssum;
         }
