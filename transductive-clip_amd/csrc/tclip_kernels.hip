@@ -1267,6 +1267,20 @@ __global__ void k_argmin_rows(const float* __restrict__ x, int rows, int K, int3
     labels[r] = best_k;
 }
 
+// labels[r] = torch.argmax of row r: first maximum, a NaN counts as the maximum (inductive_clip.py:47).
+__global__ void k_argmax_rows(const float* __restrict__ x, long rows, int K, int32_t* __restrict__ labels) {
+    const long r = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= rows) return;
+    const float* xr = x + (size_t)r * K;
+    float best = xr[0];
+    int best_k = 0;
+    for (int k = 1; k < K; k++) {
+        const float v = xr[k];
+        if (best == best && (v > best || v != v)) { best = v; best_k = k; }
+    }
+    labels[r] = best_k;
+}
+
 // HARD_KMEANS helpers.  Centroids of empty clusters are zero (hard_kmeans.py:149-152).
 __global__ void k_zero_dead_rows(const uint8_t* __restrict__ live, int TK, int K, float* __restrict__ w) {
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < (size_t)TK * K; i += (size_t)gridDim.x * blockDim.x)
@@ -2264,6 +2278,15 @@ int tclip_kl_kmeans_run(const tclip_problem* pp, const float* x_q, float* u, flo
         hipLaunchKernelGGL(k_hard_assign, dim3(T), dim3(256), 0, st, (const int32_t*)preds, Q, K, u, change);
         hipLaunchKernelGGL(k_criterion_mean, dim3(B), dim3(64), 0, st, (const float*)change, N, 0, criterions + it, p.iters);
     }
+    TCLIP_HIP(hipGetLastError());
+    return TCLIP_OK;
+}
+
+int tclip_argmax_rows(const float* x, int64_t n_rows, int32_t n_class, int32_t* labels, void* stream) {
+    if (!x || !labels || n_rows < 0 || n_class < 1) return fail(TCLIP_ERR_ARG, "bad argument to tclip_argmax_rows");
+    if (n_rows == 0) return TCLIP_OK;
+    hipLaunchKernelGGL(k_argmax_rows, dim3((unsigned)((n_rows + 255) / 256)), dim3(256), 0, (hipStream_t)stream, x, (long)n_rows,
+                       n_class, labels);
     TCLIP_HIP(hipGetLastError());
     return TCLIP_OK;
 }

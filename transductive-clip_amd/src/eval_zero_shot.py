@@ -13,6 +13,7 @@ import torch
 from src.methods.zero_shot.em_dirichlet import EM_DIRICHLET
 from src.methods.zero_shot.hard_em_dirichlet import HARD_EM_DIRICHLET
 from src.methods.zero_shot.em_gaussian import EM_GAUSSIAN
+from src.methods.zero_shot.inductive_clip import CLIP
 from src.methods.zero_shot.em_gaussian_cov import EM_GAUSSIAN_COV
 from src.methods.zero_shot.hard_kmeans import HARD_KMEANS
 from src.methods.zero_shot.kl_kmeans import KL_KMEANS
@@ -23,7 +24,7 @@ from tclip_amd import engine, sharding
 
 _METHODS = {'EM_DIRICHLET': EM_DIRICHLET, 'HARD_EM_DIRICHLET': HARD_EM_DIRICHLET, 'SOFT_KMEANS': SOFT_KMEANS,
             'HARD_KMEANS': HARD_KMEANS, 'EM_GAUSSIAN': EM_GAUSSIAN, 'EM_GAUSSIAN_COV': EM_GAUSSIAN_COV,
-            'KL_KMEANS': KL_KMEANS}
+            'KL_KMEANS': KL_KMEANS, 'CLIP': CLIP}
 
 
 class Evaluator_zero_shot:

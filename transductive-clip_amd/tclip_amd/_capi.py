@@ -34,6 +34,7 @@ _SIGNATURES = {
     "tclip_hard_kmeans_workspace_bytes": (ctypes.c_size_t, [ctypes.POINTER(Problem)]),
     "tclip_hard_kmeans_run": (ctypes.c_int, [ctypes.POINTER(Problem), _P, _P, _P, _P, _P, _P, ctypes.c_size_t, _P]),
     "tclip_kl_kmeans_run": (ctypes.c_int, [ctypes.POINTER(Problem), _P, _P, _P, _P, _P, _P, ctypes.c_size_t, _P]),
+    "tclip_argmax_rows": (ctypes.c_int, [_P, ctypes.c_int64, ctypes.c_int32, _P, _P]),
     "tclip_probability_features": (ctypes.c_int, [_P, _P, ctypes.c_int64, ctypes.c_int32, ctypes.c_int32, ctypes.c_float, _P, _P]),
     "tclip_selftest_primitives": (ctypes.c_int, [ctypes.POINTER(ctypes.c_uint64)]),
     "tclip_profile_enable": (ctypes.c_int, [ctypes.c_int]),

@@ -215,6 +215,19 @@ def run_paddle(x_q, x_s, y_s, *, iters, lambd):
     return u, v, w, preds
 
 
+def argmax_rows(x):
+    """x (..., K) f32 cuda -> int32 (...) indices of the first maximum of every row, cuda, not synchronised."""
+    _require_cuda(x, "x")
+    x = x.contiguous().float()
+    K = x.shape[-1]
+    rows = x.numel() // K
+    with torch.cuda.device(x.device):
+        labels = torch.empty(x.shape[:-1], dtype=torch.int32, device=x.device)
+        rc = _capi.lib().tclip_argmax_rows(_ptr(x), ctypes.c_int64(rows), ctypes.c_int32(K), _ptr(labels), _stream())
+        _capi.check(rc, "tclip_argmax_rows")
+    return labels
+
+
 NORM_TYPES = {"UN": 0, "L2N": 1, "CL2N": 2}
 
 
