@@ -15,6 +15,15 @@
 //   k_logits          (alpha-1) . log z contraction for rows that changed          (:37-38)
 //   k_softmax         u = softmax_k(logit + lambd*v/Q), argmax, one-hot if hard    (:142-143)
 //   k_criterion(+_mean) per-task relative change of alpha; alpha_old <- alpha      (:236-239)
+//
+// The other methods behind the same boundary reuse k_cluster_sizes, k_mstats*,
+// k_softmax and add:
+//   k_kmeans_logits_rows   squared distances to the centroids (SOFT/HARD_KMEANS, EM_GAUSSIAN, PADDLE, BDCSPN)
+//   k_mstats*<true>, k_cov_logits_rows   inverse diagonal covariances, Mahalanobis + log-det logits (EM_GAUSSIAN_COV)
+//   k_kl_centroids, k_kl_divergences, k_argmin_rows, k_hard_assign   KL_KMEANS / HARD_KMEANS assignment
+//   k_support_stats, k_div_rows   support class means (few-shot EM-Dirichlet, PADDLE, BDCSPN)
+//   k_col_mean, k_bdcspn_normalize, k_bdcspn_eta   BD-CSPN normalisation (torch's norm order) and query shift
+//   k_argmax_rows   inductive CLIP baseline
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <stdio.h>

@@ -38,7 +38,7 @@ METHOD_DEFAULTS = {
     "hard_kmeans": dict(name_method="HARD_KMEANS", iter=10, graph_matching=True, tunable=False),
     "kl_kmeans": dict(name_method="KL_KMEANS", iter=10, graph_matching=True, tunable=False),
     "em_gaussian": dict(name_method="EM_GAUSSIAN", iter=20, graph_matching=True, tunable=False),
-    "inductive_clip": dict(name_method="CLIP", iter=1, tunable=False),
+    "inductive_clip": dict(name_method="CLIP", iter=1, graph_matching=False, tunable=False),
     "em_gaussian_cov": dict(name_method="EM_GAUSSIAN_COV", iter=20, graph_matching=True, tunable=False),
     "paddle": dict(name_method="PADDLE", iter=20, lambd=0.0, tunable=True),
     "bdcspn": dict(name_method="BDCSPN", num_NN=1, norm_type="L2N", temp=30.0, tunable=True),
