@@ -199,6 +199,12 @@ int tclip_profile_collect(double* mm_busy_ms, double* mm_launch_ms_sum, int64_t*
  * restores the default.  Process-wide; results do not depend on it. */
 int tclip_debug_set_probe_chunks(int32_t chunks);
 
+/* Live rows of short rows (n_class <= 256) advance two per 32-lane group (16 rows per block) when
+ * the row list of a launch holds at least `rows` rows (default rule: enough to fill the machine),
+ * one per group otherwise.  For tests: 0 forces the two-row kernel, a huge value the one-row
+ * kernel, negative restores the default.  Process-wide; results do not depend on it. */
+int tclip_debug_set_rowset_min_rows(int32_t rows);
+
 /* Device self-test (used by tests/test_gpu_primitives.py).  out host [14]:
  *   [0] 1/x: fast exact reciprocal vs IEEE quotient, every float of a binade at 3 exponents
  *   [1] a/b: 2^29 operand pairs            [2] fused digamma(a+1), digamma of row sums vs generic

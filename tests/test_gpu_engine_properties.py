@@ -89,6 +89,33 @@ def test_limit_cycle_shortcut_is_exact(K, N, B):
         assert torch.equal(r.alpha, runs[0].alpha) and torch.equal(r.u, runs[0].u)
 
 
+@pytest.mark.parametrize("K,N,B,hard", [(10, 7, 3, False), (37, 5, 2, True), (100, 6, 2, False), (200, 3, 1, False), (33, 4, 2, False)])
+def test_two_rows_per_lane_group_is_exact(K, N, B, hard):
+    """Large row lists run the live rows two per 32-lane group (16 rows per block share the barriers
+    and the dense lgamma passes); small ones, one per group.  Forced either way on the same small
+    problem (ragged row counts, several batches, a few-shot case) the bits must not change."""
+    from tclip_amd import engine, synth
+    x_q, _ = synth.make_query_tasks(B * N, K, seed=70 + K)
+    x = x_q.cuda()
+    few = K == 33
+    xs = ys = None
+    if few:
+        xs, ys = synth.make_support(B * N, K, 2, seed=71)
+        xs, ys = xs.cuda(), ys.squeeze(2).cuda()
+    runs = []
+    try:
+        for min_rows in (2 ** 30, 0, 0):
+            engine.debug_set_rowset_min_rows(min_rows)
+            r = engine.run_em_dirichlet(x, xs, ys, n_batches=B, iters=4, iter_mm=230, lambd=int(K / 5) * 75, hard=hard)
+            torch.cuda.synchronize()
+            runs.append(r)
+    finally:
+        engine.debug_set_rowset_min_rows(-1)
+    for r in runs[1:]:
+        assert torch.equal(r.mm_iters, runs[0].mm_iters)
+        assert torch.equal(r.alpha, runs[0].alpha) and torch.equal(r.u, runs[0].u) and torch.equal(r.v, runs[0].v)
+
+
 @pytest.mark.parametrize("K,N", [(12, 3), (40, 4)])
 def test_nan_in_one_task_leaves_the_others_exact(K, N):
     """A NaN feature poisons its own task (as in the reference) and pushes every block that holds
@@ -103,6 +130,14 @@ def test_nan_in_one_task_leaves_the_others_exact(K, N):
     x_q[1, 5, 3] = float("nan")
     res = engine.run_em_dirichlet(x_q.cuda(), n_batches=1, iters=iters, iter_mm=iter_mm, lambd=lambd, hard=False)
     torch.cuda.synchronize()
+    try:        # the same through the two-rows-per-group kernel (its generic path loops over both rows)
+        engine.debug_set_rowset_min_rows(0)
+        res2 = engine.run_em_dirichlet(x_q.cuda(), n_batches=1, iters=iters, iter_mm=iter_mm, lambd=lambd, hard=False)
+        torch.cuda.synchronize()
+    finally:
+        engine.debug_set_rowset_min_rows(-1)
+    assert torch.equal(torch.nan_to_num(res2.alpha, nan=-7.0), torch.nan_to_num(res.alpha, nan=-7.0))
+    assert torch.equal(torch.nan_to_num(res2.u, nan=-7.0), torch.nan_to_num(res.u, nan=-7.0))
     ref = c_oracle.run(x_q.numpy(), iters=iters, iter_mm=iter_mm, lambd=lambd, hard=False)
     assert np.array_equal(res.mm_iters[0].cpu().numpy(), ref["mm_iters"]) and (ref["mm_iters"] == iter_mm).all()
     clean = [t for t in range(N) if t != 1]

@@ -366,9 +366,12 @@ struct MMArgs {
 // `queue` = 64*E floats of LDS private to this wave.
 // y of a row: in registers for short rows, re-read from global memory (L1/L2 hits, read-only)
 // every iteration for long rows, where 2 x E registers per lane would cost occupancy and spills.
+#ifndef TCLIP_Y_REGS_MAX_E
+#define TCLIP_Y_REGS_MAX_E 16
+#endif
 template <int E>
 struct RowY {
-    static constexpr bool kInRegs = E <= 16;
+    static constexpr bool kInRegs = E <= TCLIP_Y_REGS_MAX_E;
     float r[kInRegs ? E : 1];
     const float* g;      // row base in global memory, or nullptr for a dead row (y = -10)
     int lane, K;
@@ -589,33 +592,40 @@ __global__ __launch_bounds__(256, (E > 8 ? TCLIP_MM_WAVES_LARGE : TCLIP_MM_WAVES
 // `bad` is raised by a wave that holds an argument outside the fast domain.
 struct QueueCtl { int count[2][8]; int bad; };
 
-template <int E, int W>
-__device__ __forceinline__ void mm_iterate_block(float (&beta)[E], const RowY<E>& yv, int K, int lane, bool active,
-                                                 const LogTabEntry* tab, float* queue, QueueCtl* ctl, int turn,
-                                                 bool measure, double& num, double& den) {
+template <int E, int W, int R>
+__device__ __forceinline__ void mm_iterate_block(float (&beta)[R][E], const RowY<E> (&yv)[R], int K, int lane,
+                                                 const bool (&active)[R], const LogTabEntry* tab, float* queue, QueueCtl* ctl,
+                                                 int turn, bool measure, double (&num)[R], double (&den)[R]) {
     const int wave = threadIdx.x >> 6, lane64 = threadIdx.x & 63;
-    float s = 16.0f;
+    float s[R];
     bool in_domain = true;
-    if (active) {
-        s = group_sum_torch<E>(beta, K, lane);
-        in_domain = fast_range_f32(s) && s <= 0x1p40f;
+    // phase A: queue the arguments of the expensive lgamma branch in this wave's slice (row set by row set)
+    float* slice = queue + wave * (64 * E * R);
+    int base[R + 1];
+    base[0] = 0;
 #pragma unroll
-        for (int e = 0; e < E; e++) in_domain = in_domain && mm_fast_domain(beta[e]);
-    }
-    // phase A: queue the arguments of the expensive lgamma branch in this wave's slice
-    float* slice = queue + wave * (64 * E);
-    int idx = 0;
+    for (int r = 0; r < R; r++) {
+        s[r] = 16.0f;
+        if (active[r]) {
+            s[r] = group_sum_torch<E>(beta[r], K, lane);
+            in_domain = in_domain && fast_range_f32(s[r]) && s[r] <= 0x1p40f;
 #pragma unroll
-    for (int e = 0; e < E; e++) {
-        const float x1 = beta[e] + 1.0f;
-        const bool big = active && x1 >= 2.3f;
-        const unsigned long long m = __ballot(big);
-        if (big) slice[idx + lanes_below(m)] = x1;
-        idx += __popcll(m);
+            for (int e = 0; e < E; e++) in_domain = in_domain && mm_fast_domain(beta[r][e]);
+        }
+        int idx = base[r];
+#pragma unroll
+        for (int e = 0; e < E; e++) {
+            const float x1 = beta[r][e] + 1.0f;
+            const bool big = active[r] && x1 >= 2.3f;
+            const unsigned long long m = __ballot(big);
+            if (big) slice[idx + lanes_below(m)] = x1;
+            idx += __popcll(m);
+        }
+        base[r + 1] = idx;
     }
     const bool wave_ok = __all(in_domain);
     if (lane64 == 0) {
-        ctl->count[turn & 1][wave] = idx;
+        ctl->count[turn & 1][wave] = base[R];
         if (!wave_ok) ctl->bad = 1;
     }
     __syncthreads();
@@ -628,18 +638,20 @@ __device__ __forceinline__ void mm_iterate_block(float (&beta)[E], const RowY<E>
     if (__builtin_expect(bad, 0)) {                             // NaN / inf / out of range somewhere in the block
         __syncthreads();                                        // everyone has seen the flag
         if (threadIdx.x == 0) ctl->bad = 0;
-        if (active) {
-            const float psi_s = digamma_f32(s);
+#pragma unroll
+        for (int r = 0; r < R; r++) {
+            if (!active[r]) continue;
+            const float psi_s = digamma_f32(s[r]);
 #pragma unroll
             for (int e = 0; e < E; e++) {
-                const float nb = mm_update_generic(beta[e], yv.get(e), psi_s);
+                const float nb = mm_update_generic(beta[r][e], yv[r].get(e), psi_s);
                 const bool ok = e * kGroup + lane < K;
                 if (measure && ok) {
-                    const double df = (double)nb - (double)beta[e];
-                    num += df * df;
-                    den += (double)beta[e] * (double)beta[e];
+                    const double df = (double)nb - (double)beta[r][e];
+                    num[r] += df * df;
+                    den[r] += (double)beta[r][e] * (double)beta[r][e];
                 }
-                beta[e] = ok ? nb : 0.0f;
+                beta[r][e] = ok ? nb : 0.0f;
             }
         }
         __syncthreads();
@@ -652,70 +664,90 @@ __device__ __forceinline__ void mm_iterate_block(float (&beta)[E], const RowY<E>
         const int j = start + lane64;                          // j-th entry of the block, slices in wave order
         int at = j;
 #pragma unroll
-        for (int w = 1; w < W; w++) at += j >= before[w] ? 64 * E - (before[w] - before[w - 1]) : 0;
+        for (int w = 1; w < W; w++) at += j >= before[w] ? 64 * E * R - (before[w] - before[w - 1]) : 0;
         const float v = j < n_big ? queue[at] : 8.0f;
         const float r = lgamma_sleef_ge23<true>(v);
         if (j < n_big) queue[at] = r;
     }
-    const float psi_s = digamma_pos_f32(s, tab);
+    float psi_s[R];
+#pragma unroll
+    for (int r = 0; r < R; r++) psi_s[r] = digamma_pos_f32(s[r], tab);
     __syncthreads();
     // phase C: per element digamma, cheap lgamma branch, pick-up, algebra
-    if (!active) return;
-    mm_apply_updates<E>(beta, yv, K, lane, psi_s, tab, slice, 0, measure, num, den);
+#pragma unroll
+    for (int r = 0; r < R; r++)
+        if (active[r]) mm_apply_updates<E>(beta[r], yv[r], K, lane, psi_s[r], tab, slice, base[r], measure, num[r], den[r]);
 }
 
 #ifndef TCLIP_MM_BLOCK_WAVES
 #define TCLIP_MM_BLOCK_WAVES 4        // waves (= pairs of rows) per block of k_mm_live for E <= 8
 #endif
+#ifndef TCLIP_MM_ROWSETS
+#define TCLIP_MM_ROWSETS 2            // rows per 32-lane group of k_mm_live for E <= 8: 16 rows share a block's two barriers and
+                                      // its dense lgamma passes (fuller passes: +2 % on the K = 100 bench; 4 rows per group spill)
+#endif
 // kDead: the listed rows are dead rows whose cache ends at this chunk: y = -10, the iterate lives in
 // `beta_dead` (their alpha keeps its value, em_dirichlet.py:224-226) and the stop-test pair goes to the cache.
-template <int E, int W, bool kDead>
+template <int E, int W, bool kDead, int R>
 __global__ __launch_bounds__(64 * W, (E > 8 ? TCLIP_MM_WAVES_LARGE : TCLIP_MM_WAVES_SMALL)) void k_mm_live(MMArgs a) {
     __shared__ LogTabEntry tab[16];
-    __shared__ float queue[64 * W * E];
+    __shared__ float queue[64 * W * E * R];
     __shared__ QueueCtl ctl;
     if (threadIdx.x == 0) ctl.bad = 0;
     load_log_table(tab);
     const int lane = threadIdx.x & (kGroup - 1);
     const int group = threadIdx.x / kGroup;
-    constexpr int kRows = 2 * W;
+    constexpr int kGroups = 2 * W, kRows = kGroups * R;
     int turn = 0;
     const int n = *a.n_rows;
     const int K = a.K;
     for (int first = blockIdx.x * kRows; first < n; first += gridDim.x * kRows) {   // block-uniform trip count
-        const int i = first + group;
-        const int row = i < n ? a.rows[i] : 0;
-        const bool active = i < n && !a.stop[row / a.rows_per_batch] && (!kDead || a.cache_len[row] == a.chunk);
-        if (!__syncthreads_or(active)) continue;                 // e.g. every batch of these rows has stopped
+        int row[R];
+        bool active[R];
+        bool any = false;
+#pragma unroll
+        for (int r = 0; r < R; r++) {
+            const int i = first + r * kGroups + group;
+            row[r] = i < n ? a.rows[i] : 0;
+            active[r] = i < n && !a.stop[row[r] / a.rows_per_batch] && (!kDead || a.cache_len[row[r]] == a.chunk);
+            any = any || active[r];
+        }
+        if (!__syncthreads_or(any)) continue;                    // e.g. every batch of these rows has stopped
         const float* src = (kDead && a.chunk > 0) ? a.beta_dead : a.alpha;
         float* dst = kDead ? a.beta_dead : a.alpha;
-        float beta[E];
-        RowY<E> yv;
-        yv.load(kDead ? nullptr : a.y + (size_t)row * K, lane, K);
+        float beta[R][E];
+        RowY<E> yv[R];
+        double num[R], den[R];
 #pragma unroll
-        for (int e = 0; e < E; e++) {
-            const int d = e * kGroup + lane;
-            beta[e] = (active && d < K) ? src[(size_t)row * K + d] : 0.0f;
+        for (int r = 0; r < R; r++) {
+            yv[r].load(kDead ? nullptr : a.y + (size_t)row[r] * K, lane, K);
+#pragma unroll
+            for (int e = 0; e < E; e++) {
+                const int d = e * kGroup + lane;
+                beta[r][e] = (active[r] && d < K) ? src[(size_t)row[r] * K + d] : 0.0f;
+            }
+            num[r] = den[r] = 0.0;
         }
-        double num = 0.0, den = 0.0;
         for (int l = a.l0; l <= a.l1; l++)
-            mm_iterate_block<E, W>(beta, yv, K, lane, active, tab, queue, &ctl, turn++, a.has_check && l == a.l1, num, den);
-        if (!active) continue;
+            mm_iterate_block<E, W, R>(beta, yv, K, lane, active, tab, queue, &ctl, turn++, a.has_check && l == a.l1, num, den);
 #pragma unroll
-        for (int e = 0; e < E; e++) {
-            const int d = e * kGroup + lane;
-            if (d < K) dst[(size_t)row * K + d] = beta[e];
-        }
-        if (a.work_counter && lane == 0)
-            atomicAdd(a.work_counter, (unsigned long long)K * (unsigned long long)(a.l1 - a.l0 + 1));
-        if (a.has_check) {
-            num = group_sum_f64(num);
-            den = group_sum_f64(den);
-            if (lane == 0) {
-                double* out = kDead ? a.cache + ((size_t)row * a.n_checks + a.chunk) * 2 : a.rowpart + 2 * (size_t)row;
-                out[0] = num;
-                out[1] = den;
-                if (kDead) a.cache_len[row] = a.chunk + 1;
+        for (int r = 0; r < R; r++) {
+            if (!active[r]) continue;
+#pragma unroll
+            for (int e = 0; e < E; e++) {
+                const int d = e * kGroup + lane;
+                if (d < K) dst[(size_t)row[r] * K + d] = beta[r][e];
+            }
+            if (a.work_counter && lane == 0)
+                atomicAdd(a.work_counter, (unsigned long long)K * (unsigned long long)(a.l1 - a.l0 + 1));
+            if (a.has_check) {
+                const double sn = group_sum_f64(num[r]), sd = group_sum_f64(den[r]);
+                if (lane == 0) {
+                    double* out = kDead ? a.cache + ((size_t)row[r] * a.n_checks + a.chunk) * 2 : a.rowpart + 2 * (size_t)row[r];
+                    out[0] = sn;
+                    out[1] = sd;
+                    if (kDead) a.cache_len[row[r]] = a.chunk + 1;
+                }
             }
         }
     }
@@ -1519,6 +1551,7 @@ struct Profile {
 };
 thread_local Profile g_prof;
 static int g_probe_chunks = TCLIP_PROBE_CHUNKS;     // tclip_debug_set_probe_chunks
+static int g_rowset_min_rows = -1;                  // tclip_debug_set_rowset_min_rows; negative: the default rule
 
 static hipEvent_t prof_event() {
     if (g_prof.used == g_prof.ev.size()) {
@@ -1605,10 +1638,20 @@ template <int E> struct LaunchMMProbe {
 };
 template <int E> struct LaunchMMLive {
     static constexpr int kWaves = E > 8 ? 4 : TCLIP_MM_BLOCK_WAVES;
+    static constexpr int kSets = E > 8 ? 1 : TCLIP_MM_ROWSETS;
     static void run(int rows, hipStream_t st, MMArgs a) {
+        // two rows per lane group only when the row list can fill the machine with the larger blocks
+        // (256 CUs x 4 blocks); `rows` is the capacity of the list, the live count is known on the device only
+        const int min_rows = g_rowset_min_rows >= 0 ? g_rowset_min_rows : 2 * kWaves * kSets * 1024;
+        if (kSets > 1 && rows >= min_rows) {
+            int grid = (rows + 2 * kWaves * kSets - 1) / (2 * kWaves * kSets);
+            if (grid > 256 * 16) grid = 256 * 16;
+            hipLaunchKernelGGL((k_mm_live<E, kWaves, false, kSets>), dim3(grid), dim3(64 * kWaves), 0, st, a);
+            return;
+        }
         int grid = (rows + 2 * kWaves - 1) / (2 * kWaves);
         if (grid > 256 * 16) grid = 256 * 16;
-        hipLaunchKernelGGL((k_mm_live<E, kWaves, false>), dim3(grid), dim3(64 * kWaves), 0, st, a);
+        hipLaunchKernelGGL((k_mm_live<E, kWaves, false, 1>), dim3(grid), dim3(64 * kWaves), 0, st, a);
     }
 };
 template <int E> struct LaunchMMDead {
@@ -1616,7 +1659,7 @@ template <int E> struct LaunchMMDead {
     static void run(int rows, hipStream_t st, MMArgs a) {
         int grid = (rows + 2 * kWaves - 1) / (2 * kWaves);
         if (grid > 256 * 16) grid = 256 * 16;
-        hipLaunchKernelGGL((k_mm_live<E, kWaves, true>), dim3(grid), dim3(64 * kWaves), 0, st, a);
+        hipLaunchKernelGGL((k_mm_live<E, kWaves, true, 1>), dim3(grid), dim3(64 * kWaves), 0, st, a);
     }
 };
 template <int E> struct LaunchRowConsts {
@@ -2309,6 +2352,11 @@ int tclip_probability_features(const float* visual, const float* text, int64_t n
     hipLaunchKernelGGL(k_probability_features, dim3((unsigned)n_rows), dim3(256), lds, (hipStream_t)stream, visual, text,
                        dim, n_class, temperature, out);
     TCLIP_HIP(hipGetLastError());
+    return TCLIP_OK;
+}
+
+int tclip_debug_set_rowset_min_rows(int32_t rows) {
+    g_rowset_min_rows = rows;
     return TCLIP_OK;
 }
 

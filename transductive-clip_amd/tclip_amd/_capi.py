@@ -39,6 +39,7 @@ _SIGNATURES = {
     "tclip_selftest_primitives": (ctypes.c_int, [ctypes.POINTER(ctypes.c_uint64)]),
     "tclip_profile_enable": (ctypes.c_int, [ctypes.c_int]),
     "tclip_debug_set_probe_chunks": (ctypes.c_int, [ctypes.c_int32]),
+    "tclip_debug_set_rowset_min_rows": (ctypes.c_int, [ctypes.c_int32]),
     "tclip_profile_collect": (ctypes.c_int, [ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_double),
                                              ctypes.POINTER(ctypes.c_int64), ctypes.POINTER(ctypes.c_int64)]),
 }

@@ -315,6 +315,12 @@ def debug_set_probe_chunks(chunks=-1):
     _capi.check(_capi.lib().tclip_debug_set_probe_chunks(int(chunks)), "tclip_debug_set_probe_chunks")
 
 
+def debug_set_rowset_min_rows(rows=-1):
+    """Test hook: row-list size from which live rows advance two per lane group (0 = always,
+    2**30 = never, negative = default rule).  Results do not depend on it."""
+    _capi.check(_capi.lib().tclip_debug_set_rowset_min_rows(int(rows)), "tclip_debug_set_rowset_min_rows")
+
+
 def profile_enable(on=True):
     _capi.check(_capi.lib().tclip_profile_enable(int(bool(on))), "tclip_profile_enable")
 
