@@ -119,3 +119,63 @@ def test_method_classes_keep_the_reference_contract():
     a.use_softmax_feature = False
     with pytest.raises(ValueError, match="unit simplex"):
         m.run_task(dict(task))
+
+
+def test_widened_entry_points_check_their_arguments():
+    """Every method entry rejects null pointers and a support size that does not fit the method
+    before any HIP call (so this runs without a GPU), with a message in tclip_last_error()."""
+    lib = _capi.lib()
+    zs = _capi.Problem(1, 4, 75, 10, 0, 5, 1, 150, 0)
+    fs = _capi.Problem(1, 4, 75, 10, 20, 5, 1, 150, 0)
+    P = ctypes.c_void_p(4096)          # never dereferenced: the checks fail first
+    none = None
+    f = ctypes.c_float(30.0)
+    assert lib.tclip_soft_kmeans_run(ctypes.byref(zs), none, f, none, none, none, none, 0, none) != 0
+    assert lib.tclip_em_gaussian_run(ctypes.byref(zs), none, f, none, none, none, none, none, 0, none) != 0
+    assert lib.tclip_em_gaussian_cov_run(ctypes.byref(zs), none, none, none, none, none, none, none, 0, none) != 0
+    assert lib.tclip_hard_kmeans_run(ctypes.byref(zs), none, none, none, none, none, none, 0, none) != 0
+    assert lib.tclip_kl_kmeans_run(ctypes.byref(zs), none, none, none, none, none, none, 0, none) != 0
+    assert lib.tclip_paddle_run(ctypes.byref(fs), none, none, none, f, none, none, none, none, none, 0, none) != 0
+    assert lib.tclip_bdcspn_run(ctypes.byref(fs), none, none, none, f, 1, none, none, none, none, 0, none) != 0
+    assert lib.tclip_argmax_rows(none, 10, 5, none, none) != 0
+    # zero-shot methods refuse a support set, few-shot methods need one
+    assert lib.tclip_em_gaussian_cov_run(ctypes.byref(fs), P, P, P, P, P, P, P, 1 << 30, none) != 0
+    assert b"zero-shot" in lib.tclip_last_error()
+    assert lib.tclip_kl_kmeans_run(ctypes.byref(fs), P, P, P, P, P, P, 1 << 30, none) != 0
+    assert b"zero-shot" in lib.tclip_last_error()
+    assert lib.tclip_bdcspn_run(ctypes.byref(zs), P, P, P, f, 1, P, P, P, P, 1 << 30, none) != 0
+    assert b"few-shot" in lib.tclip_last_error()
+    assert lib.tclip_paddle_run(ctypes.byref(zs), P, P, P, f, P, P, P, P, P, 1 << 30, none) != 0
+    assert b"few-shot" in lib.tclip_last_error()
+    assert lib.tclip_bdcspn_run(ctypes.byref(fs), P, P, P, f, 7, P, P, P, P, 1 << 30, none) != 0
+    assert b"norm_type" in lib.tclip_last_error()
+    # too small a workspace is refused
+    assert lib.tclip_bdcspn_workspace_bytes(ctypes.byref(fs)) > 0
+    assert lib.tclip_bdcspn_run(ctypes.byref(fs), P, P, P, f, 1, P, P, P, P, 16, none) != 0
+    assert b"workspace" in lib.tclip_last_error()
+
+
+def test_widened_method_classes_have_no_cpu_path():
+    from src.methods.few_shot.bdcspn import BDCSPN
+    from src.methods.few_shot.paddle import PADDLE
+    from src.methods.zero_shot.em_gaussian import EM_GAUSSIAN
+    from src.methods.zero_shot.em_gaussian_cov import EM_GAUSSIAN_COV
+    from src.methods.zero_shot.hard_kmeans import HARD_KMEANS
+    from src.methods.zero_shot.inductive_clip import CLIP
+    from src.methods.zero_shot.kl_kmeans import KL_KMEANS
+    from src.methods.zero_shot.soft_kmeans import SOFT_KMEANS
+    from src.utils import CfgNode
+    zs_task = {"x_q": torch.rand(2, 75, 20).softmax(-1), "y_q": torch.zeros(2, 75, 1, dtype=torch.int64)}
+    fs_task = dict(zs_task, x_s=torch.rand(2, 20, 20).softmax(-1), y_s=torch.arange(20).repeat(2, 1).unsqueeze(2))
+    for cls in (SOFT_KMEANS, HARD_KMEANS, KL_KMEANS, EM_GAUSSIAN, EM_GAUSSIAN_COV, CLIP):
+        a = CfgNode(iter=2, num_classes_test=20, n_class=20, n_query=75, k_eff=4, T=30, use_softmax_feature=True,
+                    graph_matching=True)
+        m = cls(model=None, device=torch.device("cpu"), log_file=None, args=a)
+        with pytest.raises(RuntimeError, match="no CPU fallback"):
+            m.run_task(dict(zs_task))
+    for cls in (PADDLE, BDCSPN):
+        a = CfgNode(iter=2, num_classes_test=20, n_class=20, n_query=75, k_eff=4, T=30, use_softmax_feature=True,
+                    graph_matching=True, lambd=1.0, norm_type="L2N", temp=30.0)
+        m = cls(model=None, device=torch.device("cpu"), log_file=None, args=a)
+        with pytest.raises(RuntimeError, match="no CPU fallback"):
+            m.run_task(dict(fs_task), shot=1)
