@@ -102,20 +102,51 @@ __device__ __forceinline__ f2 pk_lgamma_sleef_05_23(f2 x) {
 
 // lgamma on [1, 2.3) with the fp64 tail, see lgamma_sleef_1_23_f64; arguments it is not sure about
 // (6e-5 of them) send the wave through the double-float form.
+// The branch x <= 1.2 selects one of two coefficient sets.  v_cndmask_b32 issues at half the rate of
+// an fp32 FMA, so the selection is arithmetic here: with m = 1.0f (x <= 1.2) or 0.0f,
+// c = fma(m, c1 - c2, c2) is c2 for m = 0 and RN(RN(c1 - c2) + c2) for m = 1, which is c1 for every
+// pair used (checked at compile time); the fp64 tail does the same in double, where c1 - c2 is exact.
+constexpr bool sel_by_fma_is_exact(float c1, float c2) { return (c1 - c2) + c2 == c1; }
+#define TCLIP_PK_COEF(m, c1, c2) \
+    ([&]() { static_assert(sel_by_fma_is_exact(c1, c2), "coefficient pair not selectable by fma"); \
+             return pk_fma(m, pk((c1) - (c2)), pk(c2)); }())
+
+// 1.0f where x <= 1.2f, else 0.0f: one v_fma_f32 with the clamp modifier (floats above 1.2f are at
+// least one ulp = 2^-23 above it)
+__device__ __forceinline__ float le_1p2_f32(float x) {
+    constexpr float kNext = 0x1.333336p+0f;             // the float after 1.2f = 0x1.333334p+0
+    return __builtin_amdgcn_fmed3f(__builtin_fmaf(-0x1p24f, x, 0x1p24f * kNext), 0.0f, 1.0f);
+}
+
+__device__ __forceinline__ float lgamma_tail_f64_m(float u, float t, double md, bool& sure) {
+    const double td = (double)t;
+    constexpr double a1 = (double)-0.400686534596170958447352690395e+0f, a2 = (double)-0.673523028297382446749257758235e-1f;
+    constexpr double b1 = (double)+0.822466960142643054450325495997e+0f, b2 = (double)+0.322467033928981157743538726901e+0f;
+    constexpr double c1 = (double)-0.577215665946766039837398973297e+0f, c2 = (double)+0.422784335087484338986941629852e+0f;
+    static_assert((a1 - a2) + a2 == a1 && (b1 - b2) + b2 == b1 && (c1 - c2) + c2 == c1, "fp64 coefficient selection not exact");
+    double z = __builtin_fma((double)u, td, __builtin_fma(md, a1 - a2, a2));
+    z = __builtin_fma(z, td, __builtin_fma(md, b1 - b2, b2));
+    z = __builtin_fma(z, td, __builtin_fma(md, c1 - c2, c2));
+    z = z * td + 0.0;
+    const uint32_t below = (uint32_t)f64_bits(z) & 0x1fffffffu;
+    sure = (below - (0x10000000u - 0x4000u)) > 0x8000u;
+    return (float)z;
+}
+
 __device__ __forceinline__ f2 pk_lgamma_sleef_1_23(f2 x) {
-    const i2 o0 = x <= pk(1.2f);
-    const f2 t = x - pk_sel(o0, 1.0f, 2.0f);
-    f2 u = pk_sel(o0, +0.9435157776e+0f, +0.1102489550e-3f);
-    u = pk_fma(u, t, pk_sel(o0, +0.8670063615e+0f, +0.8160019934e-4f));
-    u = pk_fma(u, t, pk_sel(o0, +0.4826702476e+0f, +0.1528468856e-3f));
-    u = pk_fma(u, t, pk_sel(o0, -0.8855129778e-1f, -0.2355068718e-3f));
-    u = pk_fma(u, t, pk_sel(o0, +0.1013825238e+0f, +0.4962242092e-3f));
-    u = pk_fma(u, t, pk_sel(o0, -0.1493408978e+0f, -0.1193488017e-2f));
-    u = pk_fma(u, t, pk_sel(o0, +0.1697509140e+0f, +0.2891599433e-2f));
-    u = pk_fma(u, t, pk_sel(o0, -0.2072454542e+0f, -0.7385451812e-2f));
-    u = pk_fma(u, t, pk_sel(o0, +0.2705872357e+0f, +0.2058077045e-1f));
+    const f2 m{le_1p2_f32(x.x), le_1p2_f32(x.y)};
+    const f2 t = x - (pk(2.0f) - m);
+    f2 u = TCLIP_PK_COEF(m, +0.9435157776e+0f, +0.1102489550e-3f);
+    u = pk_fma(u, t, TCLIP_PK_COEF(m, +0.8670063615e+0f, +0.8160019934e-4f));
+    u = pk_fma(u, t, TCLIP_PK_COEF(m, +0.4826702476e+0f, +0.1528468856e-3f));
+    u = pk_fma(u, t, TCLIP_PK_COEF(m, -0.8855129778e-1f, -0.2355068718e-3f));
+    u = pk_fma(u, t, TCLIP_PK_COEF(m, +0.1013825238e+0f, +0.4962242092e-3f));
+    u = pk_fma(u, t, TCLIP_PK_COEF(m, -0.1493408978e+0f, -0.1193488017e-2f));
+    u = pk_fma(u, t, TCLIP_PK_COEF(m, +0.1697509140e+0f, +0.2891599433e-2f));
+    u = pk_fma(u, t, TCLIP_PK_COEF(m, -0.2072454542e+0f, -0.7385451812e-2f));
+    u = pk_fma(u, t, TCLIP_PK_COEF(m, +0.2705872357e+0f, +0.2058077045e-1f));
     bool s0, s1;
-    f2 r{lgamma_tail_f64(u.x, t.x, o0.x != 0, s0), lgamma_tail_f64(u.y, t.y, o0.y != 0, s1)};
+    f2 r{lgamma_tail_f64_m(u.x, t.x, (double)m.x, s0), lgamma_tail_f64_m(u.y, t.y, (double)m.y, s1)};
     if (__builtin_expect(__ballot(!(s0 && s1)) != 0ull, 0)) {
         const f2 slow = pk_lgamma_sleef_05_23(x);
         r = f2{s0 ? r.x : slow.x, s1 ? r.y : slow.y};
