@@ -1,4 +1,5 @@
-"""Randomised parity sweep on the GPU box: python3 scripts/gpu_fuzz.py [n_cases] [seed] [full]
+"""Randomised parity sweep on the GPU box: python3 scripts/gpu_fuzz.py [n_cases] [seed] [full|large]
+("large": long rows, K = 300 ... 1024, short schedules - the register-heavy instantiations)
 ("full": the reference's whole 20 x 1000 / 10 x 1000 schedule on small problems, which exercises the
 stop test at every checkpoint, dead rows, their cache and the limit-cycle shortcut)
 Random (K, Q, tasks, batches, hard, few-shot, schedule) against the C++ oracle, bit for bit, each
@@ -16,6 +17,7 @@ if "TCLIP_FUZZ_ROWSET_MIN_ROWS" in os.environ:      # 0: force the two-rows-per-
 n_cases = int(sys.argv[1]) if len(sys.argv) > 1 else 40
 rng = random.Random(int(sys.argv[2]) if len(sys.argv) > 2 else 1)
 full = len(sys.argv) > 3 and sys.argv[3] == "full"
+large = len(sys.argv) > 3 and sys.argv[3] == "large"
 bad = 0
 t0 = time.time()
 for case in range(n_cases):
@@ -26,7 +28,9 @@ for case in range(n_cases):
     B = rng.randint(1, 4)
     if full:
         K = rng.choice([2, 3, 5, 7, 8, 9, 10, 12, 16, 20, 33, 40])
-    budget = (4e8 if full else 1.5e8) / (K * K)                # element-updates the CPU oracle can afford
+    if large:
+        K, B = rng.choice([300, 397, 450, 512, 600, 640, 777, 900, 1000, 1024]), rng.randint(1, 2)
+    budget = (4e8 if full else (8e8 if large else 1.5e8)) / (K * K)                # element-updates the CPU oracle can afford
     iter_mm = 1000 if full else rng.choice([30, 51, 60, 101, 120, 151, 230])
     iters = (10 if hard else 20) if full else rng.randint(2, 4)
     N = max(1, min(6, int(budget / (iter_mm * iters * B))))
