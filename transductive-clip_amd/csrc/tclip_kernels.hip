@@ -590,7 +590,10 @@ __global__ __launch_bounds__(256, (E > 8 ? TCLIP_MM_WAVES_LARGE : TCLIP_MM_WAVES
 // both; counts are double-buffered and slices are wave-private outside the dense pass, so a wave
 // that runs ahead into the next iteration cannot disturb one that is still picking up results.
 // `bad` is raised by a wave that holds an argument outside the fast domain.
-struct QueueCtl { int count[2][8]; int bad; };
+// `rowsum` / `psi`: the row sums of the block's rows and digamma of them, double-buffered like the counts:
+// one wave evaluates digamma for all rows of the block in a single pass (one row per lane) inside the
+// dense-pass window instead of every 32-lane group evaluating its own row's value 32 times over.
+struct QueueCtl { int count[2][8]; int bad; float rowsum[2][32]; float psi[2][32]; };
 
 template <int E, int W, int R>
 __device__ __forceinline__ void mm_iterate_block(float (&beta)[R][E], const RowY<E> (&yv)[R], int K, int lane,
@@ -612,6 +615,7 @@ __device__ __forceinline__ void mm_iterate_block(float (&beta)[R][E], const RowY
 #pragma unroll
             for (int e = 0; e < E; e++) in_domain = in_domain && mm_fast_domain(beta[r][e]);
         }
+        if (lane == 0) ctl->rowsum[turn & 1][r * (2 * W) + (threadIdx.x / kGroup)] = s[r];
         int idx = base[r];
 #pragma unroll
         for (int e = 0; e < E; e++) {
@@ -669,14 +673,16 @@ __device__ __forceinline__ void mm_iterate_block(float (&beta)[R][E], const RowY
         const float r = lgamma_sleef_ge23<true>(v);
         if (j < n_big) queue[at] = r;
     }
-    float psi_s[R];
-#pragma unroll
-    for (int r = 0; r < R; r++) psi_s[r] = digamma_pos_f32(s[r], tab);
+    // digamma of the 2 W R row sums: one lane per row, by the wave after the one that opens the dense pass
+    if (wave == (W - (turn % W) + 1) % W && lane64 < 2 * W * R)
+        ctl->psi[turn & 1][lane64] = digamma_pos_f32(ctl->rowsum[turn & 1][lane64], tab);
     __syncthreads();
     // phase C: per element digamma, cheap lgamma branch, pick-up, algebra
 #pragma unroll
     for (int r = 0; r < R; r++)
-        if (active[r]) mm_apply_updates<E>(beta[r], yv[r], K, lane, psi_s[r], tab, slice, base[r], measure, num[r], den[r]);
+        if (active[r])
+            mm_apply_updates<E>(beta[r], yv[r], K, lane, ctl->psi[turn & 1][r * (2 * W) + (threadIdx.x / kGroup)], tab, slice, base[r],
+                                measure, num[r], den[r]);
 }
 
 #ifndef TCLIP_MM_BLOCK_WAVES
