@@ -224,6 +224,26 @@ def test_full_size_properties_k100_batch100():
     assert ((hard.u == 0) | (hard.u == 1)).all() and (hard.u.sum(-1) == 1).all()
 
 
+def test_bench_scale_call_equals_its_batches_run_alone():
+    """The bench workload (BASELINE configs[1]: K=100, 10 batches of 100 tasks, full schedule) in one
+    call - three stream groups, row lists long enough for the two-rows-per-group kernel - against
+    every batch run alone on the caller's stream (short row lists: the one-row kernel): identical
+    bits, so neither the grouping nor the kernel choice is visible in the results."""
+    from tclip_amd import engine, synth
+    K, N, B = 100, 100, 10
+    x_q, _ = synth.make_query_tasks(B * N, K, seed=1000)
+    x = x_q.cuda()
+    kw = dict(iters=20, iter_mm=1000, lambd=int(K / 5) * 75, hard=False)
+    full = engine.run_em_dirichlet(x, n_batches=B, **kw)
+    torch.cuda.synchronize()
+    for b in range(B):
+        single = engine.run_em_dirichlet(x[b * N:(b + 1) * N], n_batches=1, **kw)
+        for name in ("alpha", "u", "v", "preds"):
+            assert torch.equal(getattr(full, name)[b * N:(b + 1) * N], getattr(single, name)), (b, name)
+        assert torch.equal(full.mm_iters[b], single.mm_iters[0])
+        assert torch.equal(full.criterions[b], single.criterions[0])
+
+
 @pytest.mark.parametrize("name", ["eval_zs_soft_K10", "eval_zs_hard_K10", "eval_fs_soft_K10", "eval_zs_soft_kmeans_K10",
                                   "eval_zs_hard_kmeans_K10", "eval_zs_em_gaussian_K10", "eval_zs_em_gaussian_cov_K10", "eval_zs_kl_kmeans_K10", "eval_zs_clip_K10",
                                   "eval_fs_paddle_K10", "eval_fs_bdcspn_K10"])
