@@ -20,6 +20,12 @@ __global__ __launch_bounds__(256) void k(float* out, float seed) {
             if (MODE == 4) a[i] = a[i] > 0.5f ? a[(i + 1) % kChains] : c;
             if (MODE == 5) p[i] = p[i] + f2{c, c};
             if (MODE == 6) p[i] = p[i] * f2{m, m};
+            if (MODE == 7) {     // one rcp and four INDEPENDENT fmas (other chains' registers): serialised = 9.0 + 4 x 2.7, overlapped = max
+                a[i] = __builtin_amdgcn_rcpf(a[i]);
+                d[i] = d[i];
+                p[i].x = __builtin_fmaf(p[i].x, m, c); p[i].y = __builtin_fmaf(p[i].y, m, c);
+                p[(i + 1) % kChains].x = __builtin_fmaf(p[(i + 1) % kChains].x, m, c); p[(i + 1) % kChains].y = __builtin_fmaf(p[(i + 1) % kChains].y, m, c);
+            }
         }
     }
     float s = 0;
@@ -44,5 +50,6 @@ int main() {
     float* out; hipMalloc(&out, 256 * 8 * 256 * 4);
     run<0>("fma_f32", out); run<1>("pk_fma_f32", out); run<5>("pk_add_f32", out); run<6>("pk_mul_f32", out);
     run<2>("rcp_f32", out); run<3>("fma_f64", out); run<4>("cndmask", out);
+    run<7>("rcp+4fma", out);      // counted as ONE instruction group per count: compare with 9.0 + 4 x 2.7 = 19.7 (no overlap)
     return 0;
 }
