@@ -43,7 +43,7 @@ ITER_MM = 1000
 FLOP_EQ_PER_UPDATE = 48.0
 PEAK_VALU_TFLOPS = 157.3
 PEAK_HBM_GBS = 8000.0
-LANE_INSTR_PER_UPDATE = 332.0     # measured: SQ_INSTS_VALU 1.0496e11 x 64 lanes / 2.026e10 element-updates (profiles/r01_pmc_small_workload.txt)
+LANE_INSTR_PER_UPDATE = 327.0     # measured: SQ_INSTS_VALU 1.0347e11 x 64 lanes / 2.026e10 element-updates (profiles/r01_pmc_small_workload.txt)
 PEAK_LANE_INSTR_T = 39.3          # 256 CUs x 4 SIMDs x 16 lanes x 2.4 GHz, in 1e12 lane-instructions/s
 
 

@@ -67,11 +67,7 @@ __device__ __forceinline__ float group_sum_torch(const float (&x)[E], int K, int
     // scalar tail (K mod 8 elements) first, then the 8 vector lanes in order
     const int ntail = K - 8 * vec_size, tail_base = 8 * (vec_size & 3);
     float fin = 0.0f;
-#pragma unroll
-    for (int t = 0; t < 7; t++) {
-        const float tv = group_shfl(ragged, tail_base + t);
-        if (t < ntail) fin += tv;
-    }
+    for (int t = 0; t < ntail; t++) fin += group_shfl(ragged, tail_base + t);    // wave-uniform trip count (0..7)
 #pragma unroll
     for (int t = 0; t < 8; t++) fin += group_shfl(p0, t);
     return fin;
