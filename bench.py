@@ -4,23 +4,34 @@
     python bench.py [--gpus N] [--steps K] [--warmup W]
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
 
-One "step" = one pass of the hot path over one rank's workload: BASELINE.json configs[1]
-(zero-shot EM-Dirichlet, K=100 classes, 75 queries, 1000 tasks as 10 reference batches of 100,
-iter=20, iter_mm=1000, fp32) on synthetic peaked softmax features already resident in HBM,
-from the engine call to the per-task accuracies on the host (accuracy tail included), followed
-for N>1 by the single RCCL gather of the per-task predictions.  Weak scaling: every rank runs its
-own 1000 tasks (independent batches, no data-path collective).
+Headline workload = the north-star shape, BASELINE.json configs[3] as it lands on one GPU:
+zero-shot EM-Dirichlet, K=1000 classes (ImageNet-sized), 75 queries, reference batches of 125 tasks,
+iter=20, iter_mm=1000, fp32.  configs[3] is 10 000 tasks = 80 batches over 8 GPUs, i.e. 10 batches
+(1 250 tasks) per GPU; `--gpus N` runs 10*N batches (1 250*N tasks) dealt round-robin to the N ranks,
+so N=8 IS configs[3] and N=1 is its per-GPU share ("scaling": "weak": the work per GPU is fixed;
+10 000 tasks on one GPU would take two minutes per step, beyond what the driver's 25 steps allow).
+
+One "step" = one pass of the task-batch loop (reference src/eval_zero_shot.py:140-187) through
+`Evaluator_zero_shot.evaluate_tasks` of this package: device-side gather of the task rows from the
+feature table resident in HBM (indices drawn beforehand, identically on every rank, with the
+reference's sampler), one engine call for the rank's batches, the accuracy tail (device prototypes,
+host assignment), and for N>1 the single RCCL all_gather of the per-task accuracies onto rank 0.
 
 Extra objects on the JSON line:
-  roofline     the dominant kernel k_mm_live (+ its dead-row twin k_mm_chunk), timed live with HIP events around each of its
-               launches on the streams they run on (independent batches use a few internal
-               streams, so launches overlap: `achieved` divides by the time during which at least
-               one launch was running, `avg_launch_ms` is the plain mean launch duration).  The path is fp32 vector-ALU bound, so the bound is
-               "valu": achieved = 48 flop-equivalents x element-updates executed / kernel time,
-               peak = 157.3 TFLOP/s (fp32 vector, MI355X_MICROARCH.md); the compulsory HBM bytes
-               of the same launches are reported beside it as hbm_* against 8 TB/s.
-  cpu_baseline the torch-eager CPU restatement of the reference loop (oracle/ref_torch.py, same
-               op sequence as the reference; kind "port") timed on this host on a bounded sample.
+  roofline     the dominant kernel k_mm_live, timed live with HIP events around each of its launches
+               on the streams they run on (independent batches use a few internal streams, so
+               launches overlap: `achieved` divides by the time during which at least one launch
+               was running, `avg_launch_ms` is the plain mean launch duration).  The path is fp32
+               vector-ALU bound, so the bound is "valu": achieved = 48
+               flop-equivalents x element-updates executed / kernel time against 157.3 TFLOP/s.
+               `traffic` = HBM-side bytes per launch of that kernel from the PMC passes recorded in
+               profiles/pmc_current.json (FETCH_SIZE + WRITE_SIZE, calibrated on the dword-per-lane
+               copy kernel of the same run), null when that file does not describe this build.
+  secondary    the K=100 workload of round 1 (BASELINE configs[1]), a few steps, same roofline fields.
+  cpu_baseline the torch-eager CPU restatement of the reference loop (oracle/ref_torch.py, kind
+               "port") on this host: K=1000 is ~6 minutes per task on 8 cores, so, as SURVEY.md 8d
+               prescribes, 51 and 151 MM iterations plus one M/E-step are timed on a 2-task batch
+               and extrapolated over the MM schedule the GPU run recorded.
 """
 import argparse
 import json
@@ -34,17 +45,19 @@ sys.path.insert(0, os.path.join(ROOT, "transductive-clip_amd"))
 
 import torch  # noqa: E402
 
-K_CLASSES = 100
 N_QUERY = 75
-TASKS_PER_BATCH = 100
-N_BATCHES = 10
 ITERS = 20
 ITER_MM = 1000
+HEADLINE = dict(name="k1000", K=1000, tasks_per_batch=125, batches_per_gpu=10, rows_per_class=50,
+                text="EM-Dirichlet zero-shot, K=1000 (imagenet-sized), 75-query, 1250 tasks per GPU as 10 batches of 125, "
+                     "iter=20, iter_mm=1000 (BASELINE.json configs[3]: 10 000 tasks on 8 GPUs = this per GPU)")
+SECONDARY = dict(name="k100", K=100, tasks_per_batch=100, batches_per_gpu=10, rows_per_class=40,
+                 text="EM-Dirichlet zero-shot, K=100 (caltech101-sized), 75-query, 1000 tasks per GPU as 10 batches of 100, "
+                      "iter=20, iter_mm=1000 (BASELINE.json configs[1])")
 FLOP_EQ_PER_UPDATE = 48.0
 PEAK_VALU_TFLOPS = 157.3
 PEAK_HBM_GBS = 8000.0
-LANE_INSTR_PER_UPDATE = 327.0     # measured: SQ_INSTS_VALU 1.0347e11 x 64 lanes / 2.026e10 element-updates (profiles/r01_pmc_small_workload.txt)
-PEAK_LANE_INSTR_T = 39.3          # 256 CUs x 4 SIMDs x 16 lanes x 2.4 GHz, in 1e12 lane-instructions/s
+PMC_FILE = os.path.join(ROOT, "profiles", "pmc_current.json")
 
 
 _CPU_SNIPPET = r"""
@@ -55,24 +68,31 @@ from oracle import ref_torch
 from tclip_amd import synth
 torch.set_num_threads({threads})
 x_q, _ = synth.make_query_tasks({n_tasks}, {K}, seed=0)
-out = ref_torch.run(x_q, n_class={K}, iters={iters}, iter_mm={iter_mm}, lambd={lambd}, hard=False)
-print(json.dumps({{"seconds": out["seconds"], "threads": torch.get_num_threads(), "torch": torch.__version__}}))
+out = {{}}
+for mm in {mm_list}:
+    r = ref_torch.run(x_q, n_class={K}, iters={iters}, iter_mm=mm, lambd={lambd}, hard=False)
+    out[str(mm)] = r["seconds"]
+print(json.dumps({{"seconds": out, "threads": torch.get_num_threads(), "torch": torch.__version__}}))
 """
 
 
-def cpu_baseline(n_tasks=4, budget_s=240):
+def cpu_baseline(w, mm_schedule, budget_s=300):
     """Reference loop on the host CPU (kind "port": oracle/ref_torch.py issues the reference's own
-    torch op sequence), bounded sample: n_tasks tasks of the same workload in one batch, full
-    20 x 1000 schedule.  Runs in a child process under a time budget so that an oversubscribed
-    or throttled host cannot stall the benchmark."""
+    torch op sequence).  mm_schedule: MM iterations per outer iteration the GPU run recorded for
+    batch 0.  Child process under a time budget: an oversubscribed host cannot stall the bench."""
     import subprocess
     try:
         usable = len(os.sched_getaffinity(0))
     except AttributeError:
         usable = os.cpu_count() or 1
     threads = max(1, min(usable, 16))
-    code = _CPU_SNIPPET.format(root=ROOT, threads=threads, n_tasks=n_tasks, K=K_CLASSES, iters=ITERS,
-                               iter_mm=ITER_MM, lambd=int(K_CLASSES / 5) * N_QUERY)
+    K = w["K"]
+    if K >= 397:          # extrapolated: one outer iteration with 51 and with 151 MM iterations
+        n_tasks, iters, mm_list = 2, 1, [51, 151]
+    else:                 # affordable in full: one whole batch, whole schedule
+        n_tasks, iters, mm_list = w["tasks_per_batch"], ITERS, [ITER_MM]
+    code = _CPU_SNIPPET.format(root=ROOT, threads=threads, n_tasks=n_tasks, K=K, iters=iters, mm_list=mm_list,
+                               lambd=int(K / 5) * N_QUERY)
     try:
         out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=budget_s)
         info = json.loads(out.stdout.strip().splitlines()[-1])
@@ -80,9 +100,59 @@ def cpu_baseline(n_tasks=4, budget_s=240):
         return {"value": None, "unit": "tasks/s", "cores": threads, "kind": "port",
                 "sample": f"not measured: {type(e).__name__} within {budget_s}s budget"}
     secs = info["seconds"]
-    return {"value": n_tasks / secs, "unit": "tasks/s", "cores": info["threads"], "kind": "port",
-            "sample": f"{n_tasks} tasks (one batch) of the same K={K_CLASSES}, 75-query workload, full "
-                      f"{ITERS}x{ITER_MM} schedule, torch {info['torch']} CPU eager, {secs:.1f}s"}
+    if len(mm_list) == 1:
+        total = secs[str(ITER_MM)]
+        return {"value": n_tasks / total, "unit": "tasks/s", "cores": info["threads"], "kind": "port",
+                "sample": f"{n_tasks} tasks (one batch) of the same K={K}, 75-query workload, full {ITERS}x{ITER_MM} "
+                          f"schedule, torch {info['torch']} CPU eager, {total:.1f}s"}
+    t51, t151 = secs["51"], secs["151"]
+    per_mm = (t151 - t51) / 100.0                   # one MM iteration of the n_tasks batch
+    per_me = max(t51 - 51 * per_mm, 0.0)            # M-step statistics + E-step + criterion of one outer iteration
+    total = sum(per_me + n * per_mm for n in mm_schedule)
+    return {"value": n_tasks / total, "unit": "tasks/s", "cores": info["threads"], "kind": "port",
+            "sample": f"{n_tasks}-task batch of the same K={K}, 75-query workload: one outer iteration timed with 51 "
+                      f"({t51:.1f}s) and 151 ({t151:.1f}s) MM iterations -> {1e3 * per_mm:.1f} ms per MM iteration, "
+                      f"{per_me:.2f}s per M/E-step, extrapolated over the recorded schedule of "
+                      f"{int(sum(mm_schedule))} MM iterations in {len(mm_schedule)} outer iterations = {total:.0f}s "
+                      f"(SURVEY.md 8d); torch {info['torch']} CPU eager",
+            "extrapolated": True}
+
+
+def load_pmc():
+    try:
+        with open(PMC_FILE) as f:
+            return json.load(f)
+    except Exception:
+        return None
+
+
+def roofline_of(prof, steps, K, pmc_key):
+    """prof = engine.profile_collect() of `steps` timed steps."""
+    mm_ms, mm_launch_sum, mm_launches, updates = prof
+    achieved = FLOP_EQ_PER_UPDATE * updates / (mm_ms * 1e-3) / 1e12 if mm_ms > 0 else 0.0
+    # algorithmic HBM bytes of the MM launches: every listed row is read (alpha, y) and written (alpha)
+    # once per launch = 12 bytes per element per <=51-iteration launch
+    rows_bytes = 12.0 * updates / 50.0
+    hbm_gbs = rows_bytes / (mm_ms * 1e-3) / 1e9 if mm_ms > 0 else 0.0
+    out = {"bound": "valu", "kernel": "k_mm_live", "achieved": achieved, "peak": PEAK_VALU_TFLOPS, "unit": "TFLOP/s",
+           "frac": achieved / PEAK_VALU_TFLOPS, "traffic": None,
+           "flop_eq_per_element_update": FLOP_EQ_PER_UPDATE,
+           "element_updates_executed_per_step": updates / steps,
+           "element_updates_per_s": updates / (mm_ms * 1e-3) if mm_ms > 0 else 0.0,
+           "kernel_busy_ms_per_step": mm_ms / steps, "launches_per_step": mm_launches / steps,
+           "avg_launch_ms": mm_launch_sum / max(mm_launches, 1),
+           "launch_overlap": mm_launch_sum / mm_ms if mm_ms > 0 else 0.0,
+           "algorithmic_bytes_per_launch": rows_bytes / max(mm_launches, 1),
+           "hbm": {"bound": "hbm", "achieved": hbm_gbs, "peak": PEAK_HBM_GBS, "unit": "GB/s",
+                   "frac": hbm_gbs / PEAK_HBM_GBS, "algorithmic_bytes_per_step": rows_bytes / steps}}
+    pmc = load_pmc()
+    if pmc and pmc_key in pmc:
+        e = pmc[pmc_key]
+        out["traffic"] = e.get("traffic_bytes_per_launch")
+        out["traffic_source"] = {k: e.get(k) for k in ("file", "workload", "fetch_bytes_per_launch", "write_bytes_per_launch",
+                                                       "algorithmic_bytes_per_launch", "calibration", "lane_instr_per_update",
+                                                       "wait_frac", "scratch_bytes_per_lane", "commit")}
+    return out
 
 
 def main():
@@ -91,6 +161,8 @@ def main():
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-secondary", action="store_true")
+    ap.add_argument("--workload", choices=["k1000", "k100"], default="k1000", help="headline workload (k100: round-1 shape)")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -105,85 +177,89 @@ def main():
         import torch.distributed as dist
         dist.init_process_group("nccl", device_id=dev)
 
-    from tclip_amd import engine, synth
-    T = N_BATCHES * TASKS_PER_BATCH
-    x_q, y_q = synth.make_query_tasks(T, K_CLASSES, seed=1000 + rank)
-    x_q, y_q = x_q.to(dev), y_q.squeeze(2)
-    lambd = int(K_CLASSES / 5) * N_QUERY
+    import random
 
-    def step():
-        res = engine.run_em_dirichlet(x_q, n_batches=N_BATCHES, iters=ITERS, iter_mm=ITER_MM, lambd=lambd, hard=False)
-        acc, _ = engine.clustering_accuracy(x_q, res.preds, y_q, graph_matching=True)
-        if dist_on:
-            blocks = [torch.empty_like(res.preds) for _ in range(world)]
-            dist.all_gather(blocks, res.preds)     # the one exchange: per-task predictions
-        return res, acc
+    import numpy as np
+    from src.eval_zero_shot import Evaluator_zero_shot
+    from src.utils import CfgNode
+    from tclip_amd import engine, synth
 
     def fence():
         if dist_on:
             dist.barrier()
         torch.cuda.synchronize()
 
-    for _ in range(args.warmup):
-        step()
-    fence()
-    engine.profile_enable(True)
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        res, acc = step()
-    fence()
-    elapsed = time.perf_counter() - t0
-    mm_ms, mm_launch_sum, mm_launches, updates = engine.profile_collect()
-    engine.profile_enable(False)
-    if dist_on:
-        t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
+    def prepare(w, n_ranks):
+        """Feature table in HBM + the index stream of every batch (same on every rank)."""
+        K = w["K"]
+        feats, labels = synth.make_feature_table(K, w["rows_per_class"], seed=2020)
+        n_tasks = w["tasks_per_batch"] * w["batches_per_gpu"] * n_ranks
+        cfg = CfgNode(iter=ITERS, iter_mm=ITER_MM, num_classes_test=K, n_class=K, n_query=N_QUERY, k_eff=5, T=30,
+                      use_softmax_feature=True, graph_matching=True, shots=0, number_tasks=n_tasks,
+                      batch_size=w["tasks_per_batch"], name_method="EM_DIRICHLET", used_test_set="test")
+        ev = Evaluator_zero_shot(device=dev, args=cfg, log_file=None)
+        random.seed(2020); np.random.seed(2020); torch.manual_seed(2020)     # main.py:42-46
+        idx = ev.sample_indices(labels.numpy())
+        return ev, feats.to(dev), labels.to(dev), idx
 
+    def run_steps(ev, table, labels, idx, warmup, steps):
+        for _ in range(warmup):
+            ev.evaluate_tasks(None, table, labels, indices=idx)
+        fence()
+        engine.profile_enable(True)
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            acc_mean, _ = ev.evaluate_tasks(None, table, labels, indices=idx)
+        fence()
+        elapsed = time.perf_counter() - t0
+        prof = engine.profile_collect()
+        engine.profile_enable(False)
+        if dist_on:
+            t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            elapsed = float(t.item())
+        return elapsed, prof, acc_mean
+
+    head = HEADLINE if args.workload == "k1000" else SECONDARY
+    ev, table, labels, idx = prepare(head, world)
+    elapsed, prof, acc_mean = run_steps(ev, table, labels, idx, args.warmup, args.steps)
+    steps = max(args.steps, 1)
+    mm_iters = ev.last_method.mm_iters                  # (local batches, iters)
+    line = None
     if rank == 0:
-        steps = max(args.steps, 1)
-        tasks = world * T * steps
-        mm_iters = res.mm_iters.cpu().numpy()
-        # algorithmic figures: element-updates under reference semantics vs executed
-        ref_updates = float(K_CLASSES) ** 2 * TASKS_PER_BATCH * float(mm_iters.sum())
-        achieved = FLOP_EQ_PER_UPDATE * updates / (mm_ms * 1e-3) / 1e12 if mm_ms > 0 else 0.0
-        # compulsory HBM bytes of the MM launches: each processed row is read and written once per
-        # launch (alpha + y in, alpha out) = 12 bytes per element per launch
-        rows_bytes = 12.0 * updates / 50.0
+        tasks = world * head["tasks_per_batch"] * head["batches_per_gpu"] * steps
+        K = head["K"]
+        roof = roofline_of(prof, steps, K, head["name"])
+        roof["element_updates_reference_semantics_per_step"] = float(K) ** 2 * head["tasks_per_batch"] * float(mm_iters.sum())
         line = {
             "metric": "transductive tasks/sec (75-query EM-Dirichlet)",
             "value": tasks / elapsed, "unit": "tasks/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": 1e3 * elapsed / steps, "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": "EM-Dirichlet zero-shot, K=100 (caltech101-sized), 75-query, 1000 tasks "
-                                   "per GPU as 10 batches of 100, iter=20, iter_mm=1000 (BASELINE.json configs[1])",
-                       "n_class": K_CLASSES, "n_query": N_QUERY, "tasks_per_batch": TASKS_PER_BATCH,
-                       "batches_per_gpu": N_BATCHES, "parallelism": f"batch-sharded x{world}",
-                       "mean_accuracy": float(acc.mean()), "mm_iters_batch0": mm_iters[0].tolist()},
-            "roofline": {"bound": "valu", "kernel": "k_mm_live", "achieved": achieved, "peak": PEAK_VALU_TFLOPS,
-                         "unit": "TFLOP/s", "frac": achieved / PEAK_VALU_TFLOPS, "traffic": None,
-                         "flop_eq_per_element_update": FLOP_EQ_PER_UPDATE,
-                         "element_updates_executed_per_step": updates / steps,
-                         "element_updates_reference_semantics_per_step": ref_updates,
-                         "kernel_busy_ms_per_step": mm_ms / steps, "launches_per_step": mm_launches / steps,
-                         "avg_launch_ms": mm_launch_sum / max(mm_launches, 1),
-                         "launch_overlap": mm_launch_sum / mm_ms if mm_ms > 0 else 0.0,
-                         # the same launches against the VALU ISSUE rate: lane-instructions per update is a
-                         # PMC measurement (SQ_INSTS_VALU x 64 / updates, profiles/r01_pmc_small_workload.txt),
-                         # the peak is one wave64 VALU instruction per SIMD every 4 cycles at 2.4 GHz
-                         "valu_issue": {"achieved": LANE_INSTR_PER_UPDATE * updates / (mm_ms * 1e-3) / 1e12 if mm_ms > 0 else 0.0,
-                                        "peak": PEAK_LANE_INSTR_T, "unit": "T lane-instr/s",
-                                        "frac": (LANE_INSTR_PER_UPDATE * updates / (mm_ms * 1e-3) / 1e12) / PEAK_LANE_INSTR_T if mm_ms > 0 else 0.0,
-                                        "lane_instructions_per_update": LANE_INSTR_PER_UPDATE},
-                         # the same launches against the HBM roofline (north_star asks for it; the
-                         # kernel keeps rows in registers for 50 iterations, so this is tiny by design)
-                         "hbm": {"bound": "hbm", "achieved": rows_bytes / (mm_ms * 1e-3) / 1e9 if mm_ms > 0 else 0.0,
-                                 "peak": PEAK_HBM_GBS, "unit": "GB/s",
-                                 "frac": (rows_bytes / (mm_ms * 1e-3) / 1e9) / PEAK_HBM_GBS if mm_ms > 0 else 0.0,
-                                 "traffic": None, "algorithmic_bytes_per_step": rows_bytes / steps}},
+            "config": {"workload": head["text"], "n_class": K, "n_query": N_QUERY, "tasks_per_batch": head["tasks_per_batch"],
+                       "batches_per_gpu": head["batches_per_gpu"], "tasks_total": world * head["tasks_per_batch"] * head["batches_per_gpu"],
+                       "parallelism": f"batch-sharded x{world}, one all_gather of per-task accuracies",
+                       "path": "Evaluator_zero_shot.evaluate_tasks (device gather from a 50-rows-per-class synthetic table, "
+                               "engine, accuracy tail, gather)",
+                       "mean_accuracy": float(acc_mean), "mm_iters_batch0": mm_iters[0].tolist()},
+            "roofline": roof,
         }
+    del ev, table, labels, idx
+    torch.cuda.empty_cache()
+
+    if world == 1 and not args.no_secondary and args.workload == "k1000":
+        ev2, table2, labels2, idx2 = prepare(SECONDARY, 1)
+        e2, prof2, acc2 = run_steps(ev2, table2, labels2, idx2, 1, 3)
+        roof2 = roofline_of(prof2, 3, SECONDARY["K"], SECONDARY["name"])
+        line["secondary"] = {"workload": SECONDARY["text"], "value": 3 * 1000 / e2, "unit": "tasks/s", "steps": 3, "warmup": 1,
+                             "ms_per_step": 1e3 * e2 / 3, "mean_accuracy": float(acc2),
+                             "mm_iters_batch0": ev2.last_method.mm_iters[0].tolist(), "roofline": roof2}
+        del ev2, table2, labels2, idx2
+        torch.cuda.empty_cache()
+
+    if rank == 0:
         if world == 1 and not args.no_cpu_baseline:
-            line["cpu_baseline"] = cpu_baseline()
+            line["cpu_baseline"] = cpu_baseline(head, mm_iters[0].tolist())
         print(json.dumps(line), flush=True)
     if dist_on:
         dist.barrier()

@@ -33,6 +33,31 @@ void mc_lgamma_f64_form(unsigned long long* out) {
         else if (tclip::f32_bits(fast) != tclip::f32_bits(ref)) out[0]++;
     }
 }
+// floats with bit patterns lo_bits..hi_bits-1, all in [2.3, 2^41]: the fp64 form of the large-argument lgamma against
+// the double-float form.  out[0] = sure and different (must be 0), out[1] = unsure, out[2] = visited,
+// out[3] = the largest distance from the rounding midpoint (in 2^-29 ulp) at which the two forms differ,
+// whether called sure or not (the window that would have been needed).
+void mc_lgamma_ge23_f64_form(unsigned int lo_bits, unsigned int hi_bits, unsigned int stride, unsigned long long* out) {
+    unsigned long long bad = 0, unsure = 0, seen = 0, need = 0;
+#pragma omp parallel for reduction(+ : bad, unsure, seen) reduction(max : need) schedule(static)
+    for (long long bb = lo_bits; bb < (long long)hi_bits; bb += stride) {
+        const float x = tclip::bits_f32((uint32_t)bb);
+        bool sure;
+        const float fast = tclip::lgamma_sleef_ge23_f64<false>(x, sure);
+        const float ref = tclip::lgamma_sleef_ge23<false>(x);
+        seen++;
+        if (!sure) unsure++;
+        if (tclip::f32_bits(fast) != tclip::f32_bits(ref)) {
+            if (sure) bad++;
+            double pd, v;
+            (void)tclip::lgamma_sleef_ge23_f64_core<false>(x, pd, v);
+            unsigned long long d = tclip::f64_distance_from_f32_midpoint(v);
+            if (x <= 7.0f) { const unsigned long long dp = tclip::f64_distance_from_f32_midpoint(pd); d = dp < d ? dp : d; }
+            need = d > need ? d : need;
+        }
+    }
+    out[0] = bad; out[1] = unsure; out[2] = seen; out[3] = need;
+}
 // checksums of the routines over the self-test's argument streams (see tclip_selftest_inputs.h)
 void mc_checksums(unsigned long long* out) {
     for (int f = 0; f < tclip::kSelfTestFunctions; f++) out[f] = 0;

@@ -111,3 +111,18 @@ def test_lgamma_fp64_form_agrees_on_every_float_of_1_to_2p3(mc):
     assert visited == 9646899          # every float in [1, 2.3)
     assert differ == 0
     assert 0 < unsure < visited // 10000
+
+
+def test_lgamma_fp64_form_agrees_on_every_float_of_2p3_to_2e41(mc):
+    """the fp64 evaluation of Sleef's large-argument lgamma used by the MM kernel's dense pass against
+    the double-float restatement (itself bit-exact against torch above), on EVERY float of
+    [2.3, 2^41] - the whole domain the kernel can feed it (alpha + 1 with alpha <= 2^40)"""
+    import struct
+    bits = lambda v: struct.unpack("<I", struct.pack("<f", v))[0]
+    out = (ctypes.c_ulonglong * 4)()
+    mc.mc_lgamma_ge23_f64_form(ctypes.c_uint(bits(2.3)), ctypes.c_uint(bits(2.0 ** 41) + 1), ctypes.c_uint(1), out)
+    differ, unsure, visited, needed_window = list(out)
+    assert visited == bits(2.0 ** 41) + 1 - bits(2.3)          # 334 286 030 floats
+    assert differ == 0, "a 'sure' argument rounds differently in the fp64 form"
+    assert 0 < unsure < visited // 10000
+    assert needed_window <= 1 << 10, needed_window             # the window in use is 2^13

@@ -56,6 +56,15 @@ __global__ void k_copy(const float* __restrict__ s, float* __restrict__ d, size_
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) d[i] = s[i];
 }
 
+__global__ void k_one_row_list(int32_t* __restrict__ rows, int32_t* __restrict__ n) { rows[0] = 0; n[0] = 1; }
+
+// p[i] = p[0] for 0 < i < n
+__global__ void k_broadcast_first(float* p, size_t n) {
+    const float v = p[0];
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x)
+        if (i) p[i] = v;
+}
+
 // ------------------------------------------------------------------------------------------
 // Few-shot support statistics, once per run (few_shot/em_dirichlet.py:196-200 recomputes them
 // every iteration from an (N,S,K,K) temporary although they are constant):
@@ -320,13 +329,13 @@ __global__ __launch_bounds__(64) void k_mstats_rows(const float* __restrict__ u,
 // terms are incomplete (k_mm_live<.., true> iterates them).  Order inside the lists is irrelevant to the results.
 __global__ void k_build_rows(const uint8_t* __restrict__ live, const int32_t* __restrict__ cache_len, int n_rows,
                              int n_checks, int32_t* __restrict__ dead_rows, int32_t* __restrict__ live_rows,
-                             int32_t* __restrict__ counts /* [0]=dead, [1]=live */) {
+                             int32_t* __restrict__ n_dead, int32_t* __restrict__ n_live) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n_rows) return;
     const bool alive = live[i];
     const bool need = !alive && n_checks > 0 && cache_len[i] < n_checks;
-    if (need) dead_rows[atomicAdd(&counts[0], 1)] = i;
-    if (alive) live_rows[atomicAdd(&counts[1], 1)] = i;
+    if (need) dead_rows[atomicAdd(n_dead, 1)] = i;
+    if (alive) live_rows[atomicAdd(n_live, 1)] = i;
 }
 
 // ------------------------------------------------------------------------------------------
@@ -352,6 +361,12 @@ struct MMArgs {
     const int32_t* n_rows;
     const int32_t* stop;    // [B]
     unsigned long long* work_counter;   // optional: element-updates executed (instrumentation)
+    // dead rows only: the list of the NEXT chunk.  The last kernel that handles a listed row in this chunk
+    // (k_mm_live<.., true>, or k_mm_probe when it follows) appends the row if it still lacks checkpoints, so
+    // that every dead-row launch sweeps a dense list: after the probe only ~10 % of the rows that died keep
+    // iterating, and a launch over the original list ran its 8-row blocks with one or two rows active.
+    int32_t* next_rows;
+    int32_t* next_count;
     int K, rows_per_batch, chunk, l0, l1, has_check, n_checks;
 };
 
@@ -395,6 +410,16 @@ struct RowY {
 // Number of set bits of a wave mask below the calling lane (v_mbcnt_lo/hi: two instructions).
 __device__ __forceinline__ int lanes_below(unsigned long long m) {
     return (int)__builtin_amdgcn_mbcnt_hi((unsigned)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m, 0u));
+}
+
+// Sleef's large-argument lgamma on a dense pass of queued arguments: the fp64 form (tclip_math.h), and the
+// double-float original for the whole pass when some lane's argument is one of the 3e-5 the fp64 form is not
+// sure about.
+__device__ __forceinline__ float lgamma_big_dense(float v) {
+    bool sure;
+    float r = lgamma_sleef_ge23_f64<true>(v, sure);
+    if (__builtin_expect(__ballot(!sure) != 0ull, 0)) r = sure ? r : lgamma_sleef_ge23<true>(v);
+    return r;
 }
 
 // Phase C of one MM iteration: every element's digamma, the cheap lgamma branch, the pick-up of
@@ -494,7 +519,7 @@ __device__ __forceinline__ void mm_iterate(float (&beta)[E], const RowY<E>& yv, 
     for (int start = 0; start < n_big; start += n_active) {
         const int idx = start + rank;
         const float v = idx < n_big ? queue[idx] : 8.0f;
-        const float r = lgamma_sleef_ge23<true>(v);
+        const float r = lgamma_big_dense(v);
         if (idx < n_big) queue[idx] = r;
     }
     __builtin_amdgcn_wave_barrier();
@@ -538,7 +563,12 @@ __global__ __launch_bounds__(256, (E > 8 ? TCLIP_MM_WAVES_LARGE : TCLIP_MM_WAVES
     const int K = a.K;
     for (int i = blockIdx.x * groups_per_block + group; i < n; i += gridDim.x * groups_per_block) {
         const int row = a.rows[i];
-        if (a.stop[row / a.rows_per_batch] || a.cache_len[row] != a.chunk + 1) continue;
+        if (a.stop[row / a.rows_per_batch]) continue;
+        const int have = a.cache_len[row];
+        if (have != a.chunk + 1) {                                  // not iterated in this chunk: its turn comes later
+            if (a.next_rows && have < a.n_checks && lane == 0) a.next_rows[atomicAdd(a.next_count, 1)] = row;
+            continue;
+        }
         const float* ref = a.beta_dead + (size_t)row * K;          // b_{l1+1}
         float beta[E];
         RowY<E> yv;
@@ -574,6 +604,7 @@ __global__ __launch_bounds__(256, (E > 8 ? TCLIP_MM_WAVES_LARGE : TCLIP_MM_WAVES
             }
             a.cache_len[row] = a.n_checks;
         }
+        if (!period && a.next_rows && lane == 0) a.next_rows[atomicAdd(a.next_count, 1)] = row;
     }
 }
 
@@ -670,7 +701,7 @@ __device__ __forceinline__ void mm_iterate_block(float (&beta)[R][E], const RowY
 #pragma unroll
         for (int w = 1; w < W; w++) at += j >= before[w] ? 64 * E * R - (before[w] - before[w - 1]) : 0;
         const float v = j < n_big ? queue[at] : 8.0f;
-        const float r = lgamma_sleef_ge23<true>(v);
+        const float r = lgamma_big_dense(v);
         if (j < n_big) queue[at] = r;
     }
     // digamma of the 2 W R row sums: one lane per row, by the wave after the one that opens the dense pass
@@ -715,8 +746,13 @@ __global__ __launch_bounds__(64 * W, (E > 8 ? TCLIP_MM_WAVES_LARGE : TCLIP_MM_WA
         for (int r = 0; r < R; r++) {
             const int i = first + r * kGroups + group;
             row[r] = i < n ? a.rows[i] : 0;
-            active[r] = i < n && !a.stop[row[r] / a.rows_per_batch] && (!kDead || a.cache_len[row[r]] == a.chunk);
+            const bool running = i < n && !a.stop[row[r] / a.rows_per_batch];
+            const int have = (kDead && running) ? a.cache_len[row[r]] : 0;
+            active[r] = running && (!kDead || have == a.chunk);
             any = any || active[r];
+            // hand the row on to the next chunk's list (an active row ends this chunk with chunk + 1 < n_checks pairs)
+            if (kDead && a.next_rows && running && have < a.n_checks && lane == 0)
+                a.next_rows[atomicAdd(a.next_count, 1)] = row[r];
         }
         if (!__syncthreads_or(any)) continue;                    // e.g. every batch of these rows has stopped
         const float* src = (kDead && a.chunk > 0) ? a.beta_dead : a.alpha;
@@ -1521,6 +1557,13 @@ __global__ void k_selftest(unsigned long long* out) {
         const float fast = lgamma_sleef_1_23_f64(x, sure);
         b3 += sure && f32_bits(fast) != f32_bits(lgamma_sleef_05_23(x));
     }
+    // the fp64 form of the large-argument lgamma on every float of [2.3, 2^41]
+    for (uint32_t b = f32_bits(2.3f) + tid; b <= f32_bits(0x1p41f); b += nth) {
+        const float x = bits_f32(b);
+        bool sure;
+        const float fast = lgamma_sleef_ge23_f64<true>(x, sure);
+        b3 += sure && f32_bits(fast) != f32_bits(lgamma_sleef_ge23<true>(x));
+    }
     atomicAdd(&out[0], b0); atomicAdd(&out[1], b1); atomicAdd(&out[2], b2);
     atomicAdd(&out[3], b3); atomicAdd(&out[4], b4); atomicAdd(&out[5], b5);
     for (int f = 0; f < kSelfTestFunctions; f++) {
@@ -1571,7 +1614,7 @@ static hipEvent_t prof_event() {
 constexpr int kDecideSlices = 64;     // blocks per batch in the first stage of the stop test (large batches)
 struct Layout {
     size_t logz, y, alpha_old, beta_dead, sup, cnt, cs, live, rowc, logit0, cache, cache_len, rowpart, mm_rows,
-        live_rows, counts, stop, ratio, dpart, total;
+        mm_rows2, dead_counts, live_rows, counts, stop, ratio, dpart, total;
     int n_checks;
 };
 
@@ -1599,6 +1642,8 @@ static Layout make_layout(const tclip_problem& p) {
     L.cache_len = take(T * K * 4);
     L.rowpart = take(T * K * 16);
     L.mm_rows = take(T * K * 4);
+    L.mm_rows2 = take(zs ? T * K * 4 : 0);
+    L.dead_counts = take(((size_t)n_chunks_of(p.iter_mm) + 2) * 4);
     L.live_rows = take(T * K * 4);
     L.counts = take(256);
     L.stop = take((size_t)p.n_batches * 4);
@@ -1771,6 +1816,8 @@ static int enqueue_batches(const tclip_problem& p, const float* x_q, const float
     int32_t* cache_len = (int32_t*)(ws + L.cache_len);
     double* rowpart = (double*)(ws + L.rowpart);
     int32_t* mm_rows = (int32_t*)(ws + L.mm_rows);
+    int32_t* dead_list[2] = {mm_rows, zs ? (int32_t*)(ws + L.mm_rows2) : mm_rows};   // chunk c sweeps dead_list[c & 1]
+    int32_t* dead_counts = (int32_t*)(ws + L.dead_counts);                        // [chunk] length of that list
     int32_t* live_rows = (int32_t*)(ws + L.live_rows);
     int32_t* counts = (int32_t*)(ws + L.counts);
     int32_t* stop = (int32_t*)(ws + L.stop);
@@ -1789,16 +1836,19 @@ static int enqueue_batches(const tclip_problem& p, const float* x_q, const float
     if (!zs) {
         hipLaunchKernelGGL(k_support_stats, dim3(K, T), dim3(128), (size_t)S * sizeof(int), st, x_s, y_s, S, K, 1, sup, cnt);
     }
-    // E-step terms of the initial alpha = 1 for every row (rows that never come alive keep them):
-    // use the full-row list 0..TK-1 once.
+    // E-step terms of the initial alpha = 1 for every row (rows that never come alive keep them).  Every
+    // row is the same all-ones vector, so lgamma(sum) - sum lgamma is evaluated for ONE row and copied
+    // (at K = 1000 the generic lgamma over all T*K*K ones took a second per 417 tasks); the
+    // contraction with log z runs over the full-row list 0..TK-1 once.
     {
-        // live_rows <- identity, counts[1] <- TK
         TCLIP_HIP(hipMemsetAsync(counts, 0, 256, st));
+        hipLaunchKernelGGL(k_one_row_list, dim3(1), dim3(1), 0, st, mm_rows, counts + 2);
+        dispatch_E<LaunchRowConsts>(K, 1, st, (const float*)alpha, (const int32_t*)mm_rows, (const int32_t*)(counts + 2), K, rowc);
+        hipLaunchKernelGGL(k_broadcast_first, dim3(ew_grid((size_t)TK)), dim3(256), 0, st, rowc, (size_t)TK);
+        // live_rows <- identity, counts[1] <- TK
         TCLIP_HIP(hipMemsetAsync(live, 1, (size_t)TK, st));
         hipLaunchKernelGGL(k_build_rows, dim3((TK + 255) / 256), dim3(256), 0, st, live, cache_len, TK, 0, mm_rows,
-                           live_rows, counts);
-        const int g8 = (TK + 7) / 8 > 65535 * 8 ? 65535 * 8 : (TK + 7) / 8;
-        dispatch_E<LaunchRowConsts>(K, g8, st, (const float*)alpha, (const int32_t*)live_rows, (const int32_t*)(counts + 1), K, rowc);
+                           live_rows, counts, counts + 1);
         dispatch_E<LaunchLogits>(K, TK > 262144 ? 262144 : TK, st, (const float*)alpha, (const float*)logz, (const float*)rowc,
                                  (const int32_t*)live_rows, (const int32_t*)(counts + 1), Q, K, logit0);
     }
@@ -1809,14 +1859,16 @@ static int enqueue_batches(const tclip_problem& p, const float* x_q, const float
                            cs, live, v, cache_len);
         launch_mstats(st, (const float*)u, (const float*)logz, (const float*)cs, (const uint8_t*)live, (const float*)sup, (const float*)cnt, T, Q, K, y, 0);
         TCLIP_HIP(hipMemsetAsync(counts, 0, 256, st));
+        TCLIP_HIP(hipMemsetAsync(dead_counts, 0, ((size_t)n_chunks + 2) * 4, st));
         TCLIP_HIP(hipMemsetAsync(stop, 0, (size_t)B * 4, st));
         hipLaunchKernelGGL(k_build_rows, dim3((TK + 255) / 256), dim3(256), 0, st, (const uint8_t*)live,
-                           (const int32_t*)cache_len, TK, n_checks, mm_rows, live_rows, counts);
+                           (const int32_t*)cache_len, TK, n_checks, dead_list[0], live_rows, dead_counts, counts + 1);
         // ---- MM fixed point in chunks aligned with the stop-test checkpoints
         for (int c = 0; c < n_chunks; c++) {
             MMArgs a;
             a.alpha = alpha; a.beta_dead = beta_dead; a.y = y; a.live = live; a.cache_len = cache_len;
             a.cache = cache; a.rowpart = rowpart; a.rows = mm_rows; a.n_rows = counts; a.stop = stop;
+            a.next_rows = nullptr; a.next_count = nullptr;
             a.K = K; a.rows_per_batch = N * K; a.chunk = c;
             a.l0 = c == 0 ? 0 : 50 * c + 1;
             a.l1 = 50 * (c + 1) < p.iter_mm - 1 ? 50 * (c + 1) : p.iter_mm - 1;
@@ -1831,11 +1883,16 @@ static int enqueue_batches(const tclip_problem& p, const float* x_q, const float
             dispatch_E<LaunchMMLive>(K, TK, st, a);
             if (e0 && e1) TCLIP_HIP(hipEventRecord(e1, st));    // the instrumentation covers k_mm_live only
             if (zs && a.has_check) {          // dead rows only matter through their stop-test terms
-                a.rows = mm_rows; a.n_rows = counts; a.work_counter = nullptr;
-                dispatch_E<LaunchMMDead>(K, TK, st, a);
+                a.rows = dead_list[c & 1]; a.n_rows = dead_counts + c; a.work_counter = nullptr;
                 // the probe needs the row to be ON its cycle already; rows that were still approaching
                 // it after chunk 0 get a few more chances before they are left to iterate every chunk
-                if (c < g_probe_chunks && c + 1 < a.n_checks) dispatch_E<LaunchMMProbe>(K, grid, st, a);
+                const bool more = c + 1 < a.n_checks, probe = c < g_probe_chunks && more;
+                int32_t* next_rows = more ? dead_list[(c + 1) & 1] : nullptr;
+                int32_t* next_count = more ? dead_counts + c + 1 : nullptr;
+                a.next_rows = probe ? nullptr : next_rows; a.next_count = probe ? nullptr : next_count;
+                dispatch_E<LaunchMMDead>(K, TK, st, a);
+                a.next_rows = next_rows; a.next_count = next_count;
+                if (probe) dispatch_E<LaunchMMProbe>(K, grid, st, a);
             }
             const bool two_stage = a.has_check && N * K > 16384;
             if (two_stage)

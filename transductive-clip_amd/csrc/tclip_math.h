@@ -458,6 +458,95 @@ TCLIP_HD float lgamma_sleef_ge23(float a) {
     return r.x + r.y;
 }
 
+// The same function for a third of the cost (the MM kernel evaluates it for ~half of the parameters of a
+// converged row).  Sleef's result is RN32 of a double-float value v that holds ~44 good bits.  Here every fp32
+// quantity the routine's fp32 parts see (the Stirling polynomial's 1/x, the exponent split and the
+// polynomial argument of both logk2f calls, which need the hi words of x+3, of the shift product and of
+// the quotient) is reproduced exactly, while the double-float arithmetic around them is replaced by
+// fp64, which evaluates the same real expression to ~50 bits.  RN32 of the fp64 value equals RN32(v) unless
+// v lies within ~2^-43 (relative) of the midpoint of two floats - `sure` says it is 2^-40 or more away (the hi word of
+// the shift product is a rounding of the same kind and has its own window); callers send the rest through
+// lgamma_sleef_ge23.  oracle/mathcheck.cpp compares the two forms on EVERY float of [2.3, 2^41]
+// (tests/test_math_host.py; scripts/check_lgamma_ge23.py for the complete sweep) and k_selftest on the device.
+constexpr int kGe23WindowLog2 = 13;        // |position - midpoint| <= 2^13 of the 2^29 sub-float positions is "unsure" (3e-5 of the
+                                           // arguments); the largest distance at which the two forms differ anywhere in the domain is 888
+TCLIP_HD bool f64_rounds_surely_to_f32(double v, int window_log2) {
+    const uint32_t below = (uint32_t)f64_bits(v) & 0x1fffffffu;   // the 29 mantissa bits an fp32 does not keep
+    const uint32_t w = 1u << window_log2;
+    return (below - (0x10000000u - w)) > 2u * w;
+}
+// value of sleef_logk2f({hi, lo}) in fp64; `hi` is the argument's hi word, `val` its value (any fp64 rendering of hi + lo)
+template <bool kFast>
+TCLIP_HD double logk2f_f64(float hi, double val) {
+    const float dx = hi * (1.0f / 0.75f);                          // arguments here lie in [2^-11, 2^42]: never "tiny"
+    const int e = (int)((f32_bits(dx) >> 23) & 0xff) - 0x7f;
+    const float sc = bits_f32((uint32_t)(127 - e) << 23);          // 2^-e
+    const float mx = hi * sc;
+    const float nx = mx + -1.0f, dnx = mx + 1.0f;                  // hi words of m - 1 and m + 1
+    const float tq = rcp_ieee<kFast>(dnx);
+    const float xx = nx * tq;                                      // hi word of the quotient as df_div forms it
+    const float x2x = xx * xx;
+    float t = 0.2392828464508056640625f;
+    t = __builtin_fmaf(t, x2x, 0.28518211841583251953125f);
+    t = __builtin_fmaf(t, x2x, 0.400005877017974853515625f);
+    t = __builtin_fmaf(t, x2x, 0.666666686534881591796875f);
+    const double md = val * (double)sc;
+    const double N = md - 1.0, D = md + 1.0;
+    double r = (double)tq;                                          // 1/D to ~2^-23: one Newton step, then a corrected quotient
+    r = __builtin_fma(r, __builtin_fma(-D, r, 1.0), r);
+    double x = N * r;
+    x = __builtin_fma(__builtin_fma(-D, x, N), r, x);
+    constexpr double kLn2Df = (double)0.69314718246459960938f + (double)-1.904654323148236017e-09f;
+    const double x2 = x * x;
+    return __builtin_fma((double)e, kLn2Df, __builtin_fma(x2 * x, (double)t, x + x));
+}
+TCLIP_HD uint32_t f64_distance_from_f32_midpoint(double v) {
+    const uint32_t below = (uint32_t)f64_bits(v) & 0x1fffffffu;
+    return below >= 0x10000000u ? below - 0x10000000u : 0x10000000u - below;
+}
+// pd: the shift product (1 beyond 7), v: the value whose RN32 is returned
+template <bool kFast>
+TCLIP_HD float lgamma_sleef_ge23_f64_core(float a, double& pd, double& v) {
+    const bool o = a <= 7.0f;
+    const double ad = (double)a;
+    // shift product a (a+1) (a+2): its hi word is RN32 of a double-float that holds the product to ~2^-45
+    pd = o ? (ad * (ad + 1.0)) * (ad + 2.0) : 1.0;
+    const float ph = (float)pd;
+    const float xh = o ? a + 3.0f : a;                             // hi word of x + 3 (its value ad + 3 is exact in fp64)
+    const double xd = o ? ad + 3.0 : ad;
+    const float t = rcp_ieee<kFast>(xh);
+    float u = +0.000839498720672087279971000786f;
+    u = __builtin_fmaf(u, t, -5.17179090826059219329394422e-05f);
+    u = __builtin_fmaf(u, t, -0.000592166437353693882857342347f);
+    u = __builtin_fmaf(u, t, +6.97281375836585777403743539e-05f);
+    u = __builtin_fmaf(u, t, +0.000784039221720066627493314301f);
+    u = __builtin_fmaf(u, t, -0.000229472093621399176949318732f);
+    u = __builtin_fmaf(u, t, -0.002681327160493827160473958490f);
+    u = __builtin_fmaf(u, t, +0.003472222222222222222175164840f);
+    u = __builtin_fmaf(u, t, +0.083333333333333333335592087900f);
+    constexpr double kHalfLog2Pi = 0.91893853320467278056;
+    constexpr double kHalfLog2PiDf = (double)(float)kHalfLog2Pi + (double)(float)(kHalfLog2Pi - (double)(float)kHalfLog2Pi);
+    double c = __builtin_fma(xd - 0.5, logk2f_f64<kFast>(xh, xd), -xd) + kHalfLog2PiDf;
+    // corr = 1 + u t (u t is exact in fp64), divided by the shift product
+    const float ch = u * t + 1.0f;                                 // hi word of corr
+    const double cd = __builtin_fma((double)u, (double)t, 1.0);
+    const float tp = rcp_ieee<kFast>(ph);
+    const float qh = ch * tp;                                      // hi word of corr / prod as df_div forms it
+    double rp = (double)tp;
+    rp = __builtin_fma(rp, __builtin_fma(-pd, rp, 1.0), rp);
+    double qd = cd * rp;
+    qd = __builtin_fma(__builtin_fma(-pd, qd, cd), rp, qd);
+    v = c + logk2f_f64<kFast>(qh, qd);
+    return (float)v;
+}
+template <bool kFast>
+TCLIP_HD float lgamma_sleef_ge23_f64(float a, bool& sure) {
+    double pd, v;
+    const float r = lgamma_sleef_ge23_f64_core<kFast>(a, pd, v);
+    sure = (a > 7.0f || f64_rounds_surely_to_f32(pd, kGe23WindowLog2)) && f64_rounds_surely_to_f32(v, kGe23WindowLog2);
+    return r;
+}
+
 // sinpifk for 0 <= d < 0.5 (all the reflection below needs)
 TCLIP_HD F2 sleef_sinpifk_small(float d) {
     const float u4 = d * 4.0f;

@@ -14,6 +14,21 @@ from src.task_generator_few_shot import relabel
 from src.utils import Logger, compute_confidence_interval
 from tclip_amd import engine, sharding
 
+def _as_tensor(x):
+    return x if torch.is_tensor(x) else torch.as_tensor(np.asarray(x))
+
+
+def relabel_batch(x_s, x_q, y_s, y_q, use_softmax_feature):
+    xs2, xq2, ys2, yq2 = [], [], [], []
+    for t in range(x_s.shape[0]):
+        a_, b_, c_, d_ = relabel(x_s[t], x_q[t], y_s[t], y_q[t], use_softmax_feature)
+        xs2.append(a_)
+        xq2.append(b_)
+        ys2.append(c_)
+        yq2.append(d_)
+    return torch.stack(xs2, 0), torch.stack(xq2, 0), torch.stack(ys2, 0), torch.stack(yq2, 0)
+
+
 _METHODS = {'EM_DIRICHLET': EM_DIRICHLET, 'HARD_EM_DIRICHLET': HARD_EM_DIRICHLET, 'PADDLE': PADDLE, 'BDCSPN': BDCSPN}
 
 
@@ -46,44 +61,44 @@ class Evaluator_few_shot:
             s_all.append(torch.stack(list(SamplerSupport_few_shot(sampler)), 0))
         return torch.stack(s_all, 0), torch.stack(q_all, 0)
 
-    def evaluate_tasks(self, model, all_features_support, all_labels_support, all_features_query, all_labels_query):
+    def evaluate_tasks(self, model, all_features_support, all_labels_support, all_features_query, all_labels_query,
+                       indices=None):
+        """`indices`: a (support, query) index pair drawn earlier with sample_indices(); None draws it here."""
         a = self.args
         self.logger.info("=> Runnning evaluation with method {} on {} dataset".format(
             a.name_method, getattr(a, 'used_test_set', 'test')))
-        s_idx, q_idx = self.sample_indices(all_labels_support, all_labels_query)
+        dev = torch.device(self.device)
+        tab_s = _as_tensor(all_features_support).float().to(dev)
+        tab_q = _as_tensor(all_features_query).float().to(dev)
+        lab_s = _as_tensor(all_labels_support).long().cpu()
+        lab_q = _as_tensor(all_labels_query).long().cpu()
+        s_idx, q_idx = self.sample_indices(lab_s.numpy(), lab_q.numpy()) if indices is None else indices
         n_batches, N, S = s_idx.shape
         Q = q_idx.shape[2]
         mine = sharding.my_batches(n_batches)
-        dev = torch.device(self.device)
-        tab_s = torch.as_tensor(all_features_support).float().to(dev)
-        tab_q = torch.as_tensor(all_features_query).float().to(dev)
-        lab_s = torch.as_tensor(np.asarray(all_labels_support)).long()
-        lab_q = torch.as_tensor(np.asarray(all_labels_query)).long()
         K = tab_q.shape[1]
-        si, qi = s_idx[mine].reshape(-1), q_idx[mine].reshape(-1)
-        x_s = engine.gather_rows(tab_s, si).view(len(mine) * N, S, K)
-        x_q = engine.gather_rows(tab_q, qi).view(len(mine) * N, Q, K)
-        y_s, y_q = lab_s[si].view(-1, S), lab_q[qi].view(-1, Q)
-        # label re-indexing / column permutation of Tasks_Generator_few_shot.get_task, per task
-        xs2, xq2, ys2, yq2 = [], [], [], []
-        for t in range(x_s.shape[0]):
-            a_, b_, c_, d_ = relabel(x_s[t], x_q[t], y_s[t], y_q[t], a.use_softmax_feature)
-            xs2.append(a_)
-            xq2.append(b_)
-            ys2.append(c_)
-            yq2.append(d_)
-        x_s, x_q = torch.stack(xs2, 0), torch.stack(xq2, 0)
-        y_s, y_q = torch.stack(ys2, 0), torch.stack(yq2, 0)
         method = self.get_method_builder(model=model, device=self.device, args=a, log_file=self.log_file)
-        # BDCSPN normalises the features in run_task, before run_method (few_shot/bdcspn.py:165-166): run_batch does both
-        run = getattr(method, "run_batch", method.run_method)
-        run(support=x_s, query=x_q, y_s=y_s.to(dev), y_q=y_q.to(dev), n_batches=len(mine))
-        logs = method.get_logs()
-        acc = torch.from_numpy(logs['acc'][:, -1].copy()).view(len(mine), N).to(dev)
+        timestamps = 0.0
+        if mine:
+            si, qi = s_idx[mine].reshape(-1), q_idx[mine].reshape(-1)
+            x_s = engine.gather_rows(tab_s, si).view(len(mine) * N, S, K)
+            x_q = engine.gather_rows(tab_q, qi).view(len(mine) * N, Q, K)
+            y_s, y_q = lab_s[si].view(-1, S), lab_q[qi].view(-1, Q)
+            # label re-indexing / column permutation of Tasks_Generator_few_shot.get_task, per task
+            x_s, x_q, y_s, y_q = relabel_batch(x_s, x_q, y_s, y_q, a.use_softmax_feature)
+            # BDCSPN normalises the features in run_task, before run_method (few_shot/bdcspn.py:165-166): run_batch does both
+            run = getattr(method, "run_batch", method.run_method)
+            run(support=x_s, query=x_q, y_s=y_s.to(dev), y_q=y_q.to(dev), n_batches=len(mine))
+            logs = method.get_logs()
+            acc = torch.from_numpy(logs['acc'][:, -1].copy()).view(len(mine), N).to(dev)
+            timestamps = float(logs['timestamps'])
+        else:      # more ranks than batches: this rank only takes part in the gather
+            acc = torch.zeros(0, N, device=dev)
         acc = sharding.gather_batch_results(acc, n_batches)
         self.last_method = method
         if acc is None:
             return None, None
         acc = acc.cpu().numpy()
         results_task = [compute_confidence_interval(acc[b])[0] for b in range(n_batches)]
-        return np.asarray(results_task).mean(), float(logs['timestamps'])
+        self.last_task_accuracies = acc
+        return np.asarray(results_task).mean(), timestamps

@@ -22,6 +22,10 @@ from src.sampler_zero_shot import CategoriesSampler_zero_shot, SamplerQuery_zero
 from src.utils import Logger, compute_confidence_interval
 from tclip_amd import engine, sharding
 
+def _as_tensor(x):
+    return x if torch.is_tensor(x) else torch.as_tensor(np.asarray(x))
+
+
 _METHODS = {'EM_DIRICHLET': EM_DIRICHLET, 'HARD_EM_DIRICHLET': HARD_EM_DIRICHLET, 'SOFT_KMEANS': SOFT_KMEANS,
             'HARD_KMEANS': HARD_KMEANS, 'EM_GAUSSIAN': EM_GAUSSIAN, 'EM_GAUSSIAN_COV': EM_GAUSSIAN_COV,
             'KL_KMEANS': KL_KMEANS, 'CLIP': CLIP}
@@ -56,28 +60,37 @@ class Evaluator_zero_shot:
             out.append(torch.stack(list(SamplerQuery_zero_shot(sampler)), 0))
         return torch.stack(out, 0)
 
-    def evaluate_tasks(self, model, all_features_query, all_labels_query):
+    def evaluate_tasks(self, model, all_features_query, all_labels_query, indices=None):
+        """`indices`: an index tensor drawn earlier with sample_indices() (bench.py draws it outside its
+        timed region); None draws it here, as the reference's loop does.  The feature table and the
+        labels may already live on the device."""
         a = self.args
         self.logger.info("=> Runnning evaluation with method {} on {} dataset".format(
             a.name_method, getattr(a, 'used_test_set', 'test')))
-        idx = self.sample_indices(all_labels_query)                 # every rank draws the same stream
+        dev = torch.device(self.device)
+        table = _as_tensor(all_features_query).float().to(dev)
+        labels = _as_tensor(all_labels_query).long()
+        idx = self.sample_indices(labels.cpu().numpy()) if indices is None else indices   # every rank: the same stream
         n_batches, N, Q = idx.shape
         mine = sharding.my_batches(n_batches)
-        dev = torch.device(self.device)
-        table = torch.as_tensor(all_features_query).float().to(dev)
-        labels = torch.as_tensor(np.asarray(all_labels_query)).long()
-        my_idx = idx[mine].reshape(-1)
         K = table.shape[1]
-        x_q = engine.gather_rows(table, my_idx).view(len(mine) * N, Q, K)
-        y_q = labels[my_idx].view(len(mine) * N, Q)
         method = self.get_method_builder(model=model, device=self.device, args=a, log_file=self.log_file)
-        method.run_method(query=x_q, y_q=y_q.to(dev), n_batches=len(mine))   # SOFT_KMEANS has no cross-task coupling
-        logs = method.get_logs()
-        acc = torch.from_numpy(logs['acc'][:, -1].copy()).view(len(mine), N).to(dev)
+        timestamps = 0.0
+        if mine:
+            my_idx = idx[mine].reshape(-1)
+            x_q = engine.gather_rows(table, my_idx).view(len(mine) * N, Q, K)
+            y_q = labels[my_idx.to(labels.device)].view(len(mine) * N, Q)
+            method.run_method(query=x_q, y_q=y_q.to(dev), n_batches=len(mine))   # SOFT_KMEANS has no cross-task coupling
+            logs = method.get_logs()
+            acc = torch.from_numpy(logs['acc'][:, -1].copy()).view(len(mine), N).to(dev)
+            timestamps = float(logs['timestamps'])
+        else:      # more ranks than batches: this rank only takes part in the gather
+            acc = torch.zeros(0, N, device=dev)
         acc = sharding.gather_batch_results(acc, n_batches)
         self.last_method = method
         if acc is None:                                             # not rank 0
             return None, None
         acc = acc.cpu().numpy()
         results_task = [compute_confidence_interval(acc[b])[0] for b in range(n_batches)]
-        return np.asarray(results_task).mean(), float(logs['timestamps'])
+        self.last_task_accuracies = acc
+        return np.asarray(results_task).mean(), timestamps
