@@ -389,9 +389,9 @@ struct RowY {
     static constexpr bool kInRegs = E <= TCLIP_Y_REGS_MAX_E;
     float r[kInRegs ? E : 1];
     const float* g;      // row base in global memory, or nullptr for a dead row (y = -10)
-    int lane, K;
+    int lane, K, n_full; // n_full = K / 32: registers below it lie entirely inside the row (wave-uniform)
     __device__ __forceinline__ void load(const float* row_y, int lane_, int K_) {
-        g = row_y; lane = lane_; K = K_;
+        g = row_y; lane = lane_; K = K_; n_full = K_ / kGroup;
         if (kInRegs) {
 #pragma unroll
             for (int e = 0; e < (kInRegs ? E : 1); e++) {
@@ -402,8 +402,10 @@ struct RowY {
     }
     __device__ __forceinline__ float get(int e) const {
         if (kInRegs) return r[kInRegs ? e : 0];
+        if (!g) return -10.0f;                       // dead rows: y is not read by lanes beyond the row either
         const int d = e * kGroup + lane;
-        return d < K ? (g ? g[d] : -10.0f) : 0.0f;
+        if (e < n_full) return g[d];                 // uniform branch: no lane mask on the load
+        return d < K ? g[d] : 0.0f;
     }
 };
 
@@ -433,38 +435,45 @@ template <int E>
 __device__ __forceinline__ void mm_apply_updates(float (&beta)[E], const RowY<E>& yv, int K, int lane, float psi_s,
                                                  const LogTabEntry* tab, const float* queue, int base, bool measure,
                                                  double& num, double& den) {
+    const int n_full = K / kGroup;                 // registers below it hold 32 elements of the row (wave-uniform)
 #pragma unroll
     for (int p = 0; p < (TCLIP_MM_PACKED ? E / 2 : 0); p++) {
         const int e = 2 * p;
         const f2 a{beta[e], beta[e + 1]};
         const bool big0 = a.x + 1.0f >= 2.3f, big1 = a.y + 1.0f >= 2.3f;
-        const unsigned long long m0 = __ballot(big0);
+        const unsigned long long m0 = __builtin_amdgcn_ballot_w64(big0);
         const float lg0 = big0 ? queue[base + lanes_below(m0)] : 0.0f;
         base += __popcll(m0);
-        const unsigned long long m1 = __ballot(big1);
+        const unsigned long long m1 = __builtin_amdgcn_ballot_w64(big1);
         const float lg1 = big1 ? queue[base + lanes_below(m1)] : 0.0f;
         base += __popcll(m1);
         const f2 nb = pk_mm_update(a, f2{yv.get(e), yv.get(e + 1)}, pk(psi_s), f2{lg0, lg1}, tab);
-        const bool ok0 = e * kGroup + lane < K, ok1 = (e + 1) * kGroup + lane < K;
+        const bool full = e + 1 < n_full;
+        const bool ok0 = full || e * kGroup + lane < K, ok1 = full || (e + 1) * kGroup + lane < K;
         if (measure) {
             const double d0 = (double)nb.x - (double)a.x, d1 = (double)nb.y - (double)a.y;
             if (ok0) { num += d0 * d0; den += (double)a.x * (double)a.x; }
             if (ok1) { num += d1 * d1; den += (double)a.y * (double)a.y; }
         }
-        beta[e] = ok0 ? nb.x : 0.0f;
-        beta[e + 1] = ok1 ? nb.y : 0.0f;
+        if (full) {                                // uniform branch: nothing to mask
+            beta[e] = nb.x;
+            beta[e + 1] = nb.y;
+        } else {
+            beta[e] = ok0 ? nb.x : 0.0f;
+            beta[e + 1] = ok1 ? nb.y : 0.0f;
+        }
     }
 #pragma unroll
     for (int e = (TCLIP_MM_PACKED ? E / 2 * 2 : 0); e < E; e++) {
         const float a = beta[e];
         const float x1 = a + 1.0f;
         const bool big = x1 >= 2.3f;
-        const unsigned long long m = __ballot(big);
+        const unsigned long long m = __builtin_amdgcn_ballot_w64(big);
         const float lg_big = big ? queue[base + lanes_below(m)] : 0.0f;
         base += __popcll(m);
         bool sure;
         float lg_small = lgamma_sleef_1_23_f64(big ? 2.0f : x1, sure);
-        if (__builtin_expect(__ballot(!sure) != 0ull, 0)) lg_small = sure ? lg_small : lgamma_sleef_05_23(big ? 2.0f : x1);
+        if (__builtin_expect(__builtin_amdgcn_ballot_w64(!sure) != 0ull, 0)) lg_small = sure ? lg_small : lgamma_sleef_05_23(big ? 2.0f : x1);
         const float psi1 = digamma_xp1(a, tab);
         const float nb = mm_update_algebra(a, yv.get(e), psi_s, psi1, big ? lg_big : lg_small);
         const bool ok = e * kGroup + lane < K;
@@ -652,7 +661,7 @@ __device__ __forceinline__ void mm_iterate_block(float (&beta)[R][E], const RowY
         for (int e = 0; e < E; e++) {
             const float x1 = beta[r][e] + 1.0f;
             const bool big = active[r] && x1 >= 2.3f;
-            const unsigned long long m = __ballot(big);
+            const unsigned long long m = __builtin_amdgcn_ballot_w64(big);
             if (big) slice[idx + lanes_below(m)] = x1;
             idx += __popcll(m);
         }
