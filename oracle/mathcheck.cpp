@@ -65,3 +65,17 @@ void mc_checksums(unsigned long long* out) {
         for (int f = 0; f < tclip::kSelfTestFunctions; f++) out[f] += tclip::selftest_term(f, i, tclip::kLogTab);
 }
 }
+
+// torch's x.norm(p=2, dim=-1) order on the AVX-512 fixture host (see row_norm_torch in tclip_kernels.hip): eight fused
+// accumulators by element index mod 8, added in order, then the tail (first four as product + add, rest fused)
+extern "C" float mc_norm8(const float* x, long n) {
+    float acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    const long nv = n & ~7L;
+    for (long d = 0; d < nv; d++) acc[d & 7] = __builtin_fmaf(x[d], x[d], acc[d & 7]);
+    float b = acc[0];
+    for (int l = 1; l < 8; l++) b += acc[l];
+    long d = nv;
+    if (n - d >= 4) for (int k = 0; k < 4; k++, d++) b = b + x[d] * x[d];
+    for (; d < n; d++) b = __builtin_fmaf(x[d], x[d], b);
+    return sqrtf(b);
+}

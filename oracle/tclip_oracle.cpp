@@ -157,6 +157,7 @@ inline void mm_step_row(const float* beta, const float* y, float* next, int K) {
 
 }  // namespace
 
+static double g_min_stop_margin = 1e300;
 extern "C" {
 
 // Runs the whole loop for ONE reference batch of n_task tasks.
@@ -241,6 +242,10 @@ int tclip_oracle_run(const float* z, const float* xs, const int64_t* ys, int N, 
                     den += (double)beta[i] * (double)beta[i];
                 }
                 const float nn = (float)sqrt(num), dn = (float)sqrt(den);
+                {   // how close this run's stop tests came to the threshold (tests/golden/find_borderline.py)
+                    const double m = fabs((double)((nn * nn) / (dn * dn)) / 1e-11 - 1.0);
+                    if (m < g_min_stop_margin) g_min_stop_margin = m;
+                }
                 if ((nn * nn) / (dn * dn) < 1e-11f) break;
             }
             beta.swap(next);
@@ -369,4 +374,10 @@ extern "C" void tclip_oracle_softmax_row(const float* x, float* out, long n) {
     for (long i = 0; i < n; i++) out[i] = tclip::exp_f32_sleef(x[i] - mx);
     const float inv = 1.0f / sum_reduce_all(out, n);
     for (long i = 0; i < n; i++) out[i] *= inv;
+}
+
+extern "C" double tclip_oracle_min_stop_margin(int reset) {
+    const double m = g_min_stop_margin;
+    if (reset) g_min_stop_margin = 1e300;
+    return m;
 }

@@ -80,6 +80,9 @@ SMALL = {
     "fs_soft_K37_N3_s2": ("fs_soft", 37, 3, 20, 2, 2021, True),
     "fs_hard_K10_N4_s4": ("fs_hard", 10, 4, 10, 4, 2020, True),
     "fs_hard_K37_N3_s3": ("fs_hard", 37, 3, 10, 3, 2021, True),
+    # few-shot at BASELINE class counts (caltech101-sized): 4-shot, S = 400 support rows
+    "fs_soft_K100_N4_s4": ("fs_soft", 100, 4, 20, 4, 2060, True),
+    "fs_hard_K100_N3_s4": ("fs_hard", 100, 3, 10, 4, 2061, True),
     "zs_skm_K10_N4": ("zs_skm", 10, 4, 20, 0, 2020, True),
     "zs_skm_K37_N6": ("zs_skm", 37, 6, 20, 0, 2021, True),
     "zs_skm_K100_N4": ("zs_skm", 100, 4, 20, 0, 2022, True),
@@ -129,6 +132,9 @@ LARGE = {
     "zs_soft_K397_N1": ("zs_soft", 397, 1, 20, 0, 2024, False),
     "zs_hard_K1000_N1": ("zs_hard", 1000, 1, 10, 0, 2025, False),
     "zs_soft_K1000_N1": ("zs_soft", 1000, 1, 20, 0, 2026, False),
+    # few-shot at sun397 / imagenet class counts (the reference's (N,S,K,K) temporary is 0.5 GB / 4 GB here)
+    "fs_soft_K397_N1_s2": ("fs_soft", 397, 1, 20, 2, 2062, False),
+    "fs_soft_K1000_N1_s1": ("fs_soft", 1000, 1, 20, 1, 2063, False),
 }
 
 
@@ -238,6 +244,8 @@ def run_case(name, spec, classes):
         a64 = alpha.astype(np.float64)
         out["alpha_rowsum"] = a64.sum(-1)
         out["alpha_rowsumsq"] = (a64 * a64).sum(-1)
+        import hashlib
+        out["alpha_sha1"] = hashlib.sha1(np.ascontiguousarray(alpha).tobytes()).hexdigest()   # every bit of alpha
     path = os.path.join(HERE, name + ".npz")
     np.savez_compressed(path, **out)
     print(f"{name}: {dt:.1f}s mm_iters={out['mm_iters'].tolist()} acc={out['acc'].ravel().round(3).tolist()} "

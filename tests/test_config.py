@@ -1,0 +1,83 @@
+"""CPU: the reference's configuration handling (main.py:19-35, src/utils.py:90-168) on own fixture YAMLs:
+three files merged in order, --opts applied before (to pick the files) and after (to win), type rule."""
+import os
+
+import numpy as np
+import pytest
+
+from src.utils import CfgNode, load_cfg_from_cfg_file, load_merged_config, merge_cfg_from_list
+
+CONFIG = os.path.join(os.path.dirname(os.path.abspath(__file__)), "fixtures", "config")
+
+
+def test_yaml_sections_are_flattened():
+    cfg = load_cfg_from_cfg_file(os.path.join(CONFIG, "datasets_config", "config_toyset.yaml"))
+    assert isinstance(cfg, CfgNode) and cfg.dataset == "toyset" and cfg.seed == 2020 and cfg.cuda is True
+    with pytest.raises(AssertionError):
+        load_cfg_from_cfg_file(os.path.join(CONFIG, "missing.yaml"))
+
+
+def test_three_file_merge_order():
+    cfg = load_merged_config(CONFIG)
+    assert cfg.method == "em_dirichlet" and cfg.name_method == "EM_DIRICHLET"
+    assert cfg.iter == 20                       # method file over main file
+    assert cfg.k_eff == 4                       # dataset file over main file
+    assert cfg.n_class == cfg.num_classes_test == 10
+    assert cfg.number_tasks == 8 and cfg.save_results is False
+
+
+def test_opts_pick_the_files_and_win_over_them():
+    cfg = load_merged_config(CONFIG, ["method", "hard_em_dirichlet", "dataset", "otherset", "k_eff", "9", "iter", "2",
+                                      "SOME.nested.new_key", "[1, 2]", "note", "free text"])
+    assert cfg.name_method == "HARD_EM_DIRICHLET"        # the method file named on the command line was read
+    assert cfg.num_classes_test == 37 and cfg.seed == 11  # and the dataset file
+    assert cfg.k_eff == 9                                # set before the merge (5 -> 9), overwritten by the dataset/method files (6), set again
+    assert cfg.iter == 2
+    assert cfg.new_key == [1, 2] and cfg.note == "free text"      # unknown keys are added, only the last component counts
+    # without the override the method file wins over dataset and main
+    assert load_merged_config(CONFIG, ["method", "hard_em_dirichlet"]).k_eff == 6
+
+
+def test_override_must_keep_the_type():
+    cfg = load_cfg_from_cfg_file(os.path.join(CONFIG, "main_config.yaml"))
+    with pytest.raises(ValueError):
+        merge_cfg_from_list(cfg, ["number_tasks", "many"])          # str for int
+    with pytest.raises(ValueError):
+        merge_cfg_from_list(cfg, ["T", "30.5"])                     # float for int
+    out = merge_cfg_from_list(cfg, ["probe_list", "(3, 4)", "use_softmax_feature", "False"])
+    assert out.probe_list == [3, 4] and out.use_softmax_feature is False and cfg.use_softmax_feature is True
+    with pytest.raises(AssertionError):
+        merge_cfg_from_list(cfg, ["number_tasks"])
+
+
+def test_main_features_reads_the_yaml_tree(tmp_path):
+    import sys
+    from conftest import PKG
+    sys.path.insert(0, PKG)
+    import main_features
+    ns, cfg = main_features.parse_args(["--query", "x.plk", "--config-root", CONFIG, "--results-root", str(tmp_path),
+                                        "--opts", "method", "paddle", "shots", "2", "lambd", "3.5"])
+    assert cfg.name_method == "PADDLE" and cfg.tunable is True and cfg.lambd == 3.5 and cfg.shots == 2
+    assert cfg.results_root == str(tmp_path)
+    # built-in defaults when no config directory is given: the same override rules
+    ns, cfg = main_features.parse_args(["--query", "x.plk", "--opts", "method", "hard_em_dirichlet", "number_tasks", "20"])
+    assert cfg.name_method == "HARD_EM_DIRICHLET" and cfg.iter == 10 and cfg.number_tasks == 20
+
+
+def test_tuned_parameter_comes_from_the_validation_sweep(tmp_path):
+    """eval_few_shot.py:152-187: the last best row of results_few_shot/val/<dataset>/<METHOD>_softmax_s<shots>.txt;
+    imagenet reads caltech101's file; no file is an error."""
+    import torch
+    from src.eval_few_shot import Evaluator_few_shot
+    a = CfgNode(dataset="imagenet", name_method="PADDLE", use_softmax_feature=True, shots=4, lambd=0.0,
+                results_root=str(tmp_path), tunable=True, used_test_set="test")
+    ev = Evaluator_few_shot(torch.device("cpu"), a, None)
+    with pytest.raises(ValueError):
+        ev.set_method_opt_param()
+    d = tmp_path / "results_few_shot" / "val" / "caltech101"
+    d.mkdir(parents=True)
+    (d / "PADDLE_softmax_s4.txt").write_text("val_param\tacc\n\t\n0.0\t71.2\t\n5.0\t80.1\t\n10.0\t80.1\t\n20.0\t79.0\t\n")
+    assert ev.set_method_opt_param() == 10.0 and a.lambd == 10.0
+    a.name_method, a.temp = "BDCSPN", 30.0
+    (d / "BDCSPN_softmax_s4.txt").write_text("val_param\tacc\n\t\n15.0\t60.0\t\n")
+    assert ev.set_method_opt_param() == 15.0 and a.temp == 15.0

@@ -82,3 +82,26 @@ def test_batch_sharding_two_ranks_gloo(tmp_path):
     got = torch.load(out)
     want = torch.tensor([[10.0 * b + j for j in range(3)] for b in range(5)])
     assert torch.equal(got, want)
+
+
+def _worker_idle_rank(rank, world, port, out):
+    """more ranks than batches: the idle rank hands an empty block to the one gather"""
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    n_batches = 1
+    mine = sharding.my_batches(n_batches)
+    assert mine == ([0] if rank == 0 else [])
+    local = torch.full((len(mine), 4), 7.0)
+    got = sharding.gather_batch_results(local, n_batches)
+    if rank == 0:
+        torch.save(got, out)
+    else:
+        assert got is None
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_more_ranks_than_batches_gloo(tmp_path):
+    out = str(tmp_path / "gathered.pt")
+    mp.spawn(_worker_idle_rank, args=(2, 29500 + ((os.getpid() + 991) % 2000), out), nprocs=2, join=True)
+    assert torch.equal(torch.load(out), torch.full((1, 4), 7.0))

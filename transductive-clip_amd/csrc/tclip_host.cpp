@@ -88,6 +88,10 @@ extern "C" int tclip_match_clusters_host(int32_t T, int32_t Q, int32_t K, const 
         if (C < 1 || C > Cmax) return TCLIP_ERR_ARG;
         const int32_t* ids = cluster_ids + (size_t)t * Cmax;
         const float* pr = prototypes + (size_t)t * Cmax * K;
+        for (int c = 0; c < C; c++)
+            if (ids[c] < 0 || ids[c] >= K) return TCLIP_ERR_ARG;             // labels index the look-up table below
+        for (int q = 0; q < Q; q++)
+            if (preds[(size_t)t * Q + q] < 0 || preds[(size_t)t * Q + q] >= K) return TCLIP_ERR_ARG;
         std::fill(lut.begin(), lut.end(), 0);
         if (graph_matching) {
             cost.resize((size_t)C * K);

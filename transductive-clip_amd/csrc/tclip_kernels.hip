@@ -1109,18 +1109,24 @@ __global__ __launch_bounds__(256) void k_softmax(const float* logit0, const floa
     const float inv = 1.0f / total;
     const float sgn = pick_min ? -1.0f : 1.0f;       // compare sgn * u: softmax values lie in [0, 1]
     float best = -2.0f;
-    int best_k = 0x7fffffff;
+    int best_k = 0x7fffffff, first_nan = 0x7fffffff;
     for (int k = lane; k < K; k += 16) {
         const float uv = ur[k] * inv;
         ur[k] = uv;
         if (sgn * uv > best) { best = sgn * uv; best_k = k; }
+        if (uv != uv && k < first_nan) first_nan = k;
     }
 #pragma unroll
     for (int m = 8; m >= 1; m >>= 1) {
         const float ob = __shfl_xor(best, m, 16);
         const int ok = __shfl_xor(best_k, m, 16);
         if (ob > best || (ob == best && ok < best_k)) { best = ob; best_k = ok; }
+        const int on = __shfl_xor(first_nan, m, 16);
+        first_nan = on < first_nan ? on : first_nan;
     }
+    // torch.argmax / argmin treat a NaN as the extremum and return the first one (features off the simplex give
+    // NaN rows: log of a negative number); the prediction is used as an index later, so it must lie in [0, K)
+    if (first_nan < K) best_k = first_nan;
     if (hard)
         for (int k = lane; k < K; k += 16) ur[k] = (k == best_k) ? 1.0f : 0.0f;
     if (lane == 0) preds[r] = best_k;
@@ -1420,7 +1426,8 @@ __global__ void k_gather_prototypes(const int32_t* __restrict__ preds, const flo
     if (threadIdx.x == 0) {
         int c = 0;
         for (int q = 0; q < Q; q++) {
-            const int p = preds[(size_t)t * Q + q];
+            int p = preds[(size_t)t * Q + q];
+            p = p < 0 ? 0 : (p >= K ? K - 1 : p);          // never index outside the task (the host side rejects such labels)
             bool seen = false;
             for (int i = 0; i < c; i++) seen |= ids[i] == p;
             if (!seen) ids[c++] = p;
@@ -1944,21 +1951,28 @@ struct StreamPool {
 };
 thread_local StreamPool g_pool;
 
-static int pool_init() {
+// Streams and join events are created on first use, only as many as a call needs (group 0 is the caller's stream).
+static int pool_init(int groups) {
     int dev = 0;
     TCLIP_HIP(hipGetDevice(&dev));
-    if (g_pool.ready && g_pool.device == dev) return TCLIP_OK;
-    if (g_pool.ready) {                       // the calling thread moved to another device
-        for (int i = 0; i < kMaxGroups; i++) { (void)hipStreamDestroy(g_pool.s[i]); (void)hipEventDestroy(g_pool.join[i]); }
+    if (g_pool.ready && g_pool.device != dev) {                       // the calling thread moved to another device
+        for (int i = 0; i < kMaxGroups; i++) {
+            if (g_pool.s[i]) (void)hipStreamDestroy(g_pool.s[i]);
+            if (g_pool.join[i]) (void)hipEventDestroy(g_pool.join[i]);
+            g_pool.s[i] = nullptr;
+            g_pool.join[i] = nullptr;
+        }
         (void)hipEventDestroy(g_pool.fork);
+        g_pool.fork = nullptr;
         g_pool.ready = false;
     }
     g_pool.device = dev;
-    for (int i = 0; i < kMaxGroups; i++) {
+    if (!g_pool.fork) TCLIP_HIP(hipEventCreateWithFlags(&g_pool.fork, hipEventDisableTiming));
+    for (int i = 1; i < groups && i < kMaxGroups; i++) {
+        if (g_pool.s[i]) continue;
         TCLIP_HIP(hipStreamCreateWithFlags(&g_pool.s[i], hipStreamNonBlocking));
         TCLIP_HIP(hipEventCreateWithFlags(&g_pool.join[i], hipEventDisableTiming));
     }
-    TCLIP_HIP(hipEventCreateWithFlags(&g_pool.fork, hipEventDisableTiming));
     g_pool.ready = true;
     return TCLIP_OK;
 }
@@ -2021,7 +2035,7 @@ int tclip_em_dirichlet_run(const tclip_problem* pp, const float* x_q, const floa
     hipStream_t caller = (hipStream_t)stream;
     const int G = n_groups_of(p);
     if (G > 1) {
-        if (int rc = pool_init()) return rc;
+        if (int rc = pool_init(G)) return rc;
         TCLIP_HIP(hipEventRecord(g_pool.fork, caller));
     }
     const size_t N = p.tasks_per_batch, Q = p.n_query, K = p.n_class, S = p.n_support;
@@ -2042,8 +2056,12 @@ int tclip_em_dirichlet_run(const tclip_problem* pp, const float* x_q, const floa
         if (int rc = enqueue_batches(qs, x_q + t0 * Q * K, zs ? nullptr : x_s + t0 * S * K, zs ? nullptr : y_s + t0 * S,
                                      u + t0 * Q * K, v + t0 * K, alpha + t0 * K * K, preds + t0 * Q,
                                      criterions + (size_t)b0 * p.iters, mm_iters + (size_t)b0 * p.iters,
-                                     (char*)workspace + ws_off[g], st))
+                                     (char*)workspace + ws_off[g], st)) {
+            // kernels already enqueued on the internal streams still use the caller's buffers: let them finish
+            // before the error reaches a caller who may free them (the caller's own stream is ordered anyway)
+            for (int h = 1; h < G; h++) (void)hipStreamSynchronize(g_pool.s[h]);
             return rc;
+        }
         if (g != 0) TCLIP_HIP(hipEventRecord(g_pool.join[g], st));
     }
     for (int g = 1; g < G; g++) TCLIP_HIP(hipStreamWaitEvent(caller, g_pool.join[g], 0));

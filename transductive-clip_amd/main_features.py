@@ -8,15 +8,19 @@ src/utils.py:266-267) can run the task loop from them:
     python main_features.py --query test_softmax_RN50_T30.plk [--support train_softmax_RN50_T30.plk] \\
         --opts method em_dirichlet dataset caltech101 number_tasks 1000 batch_size 100 shots 0
 
-`--opts k v ...` follows main.py:24-33 (values are literal-eval'ed); defaults are those of
-config/main_config.yaml and config/methods_config/{em_dirichlet,hard_em_dirichlet,soft_kmeans,hard_kmeans}.yaml.
+Configuration follows main.py:19-35: with `--config-root DIR` (or a `config/` directory in the working
+directory) the reference-format YAML files are read - DIR/main_config.yaml, then `--opts`, then
+DIR/datasets_config/config_<dataset>.yaml and DIR/methods_config/<method>.yaml, then `--opts` again, so
+the command line wins over all three files (values are literal-eval'ed, an override must keep the type of
+the value it replaces).  Without a config directory the built-in copies of the reference's defaults below are
+used the same way.  Test-split runs of a tunable few-shot method (PADDLE, BDCSPN) need the validation sweep
+file under <results-root>/results_few_shot/val/, exactly as the reference does.
 Under `python -m torch.distributed.run --nproc-per-node N` batches are sharded over N GPUs.
 """
 import argparse
 import os
 import random
 import sys
-from ast import literal_eval
 
 import numpy as np
 import torch
@@ -25,7 +29,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 if HERE not in sys.path:
     sys.path.insert(0, HERE)
 
-from src.utils import CfgNode, Logger  # noqa: E402
+from src.utils import CfgNode, Logger, load_merged_config, merge_cfg_from_list  # noqa: E402
 from tclip_amd import features, reporting  # noqa: E402
 
 MAIN_DEFAULTS = dict(dataset="synthetic", method="em_dirichlet", number_tasks=5, batch_size=5, k_eff=5, n_query=75,
@@ -45,30 +49,29 @@ METHOD_DEFAULTS = {
 }
 
 
-def _decode(v):
-    try:
-        return literal_eval(v)
-    except (ValueError, SyntaxError):
-        return v
-
-
 def parse_args(argv=None):
     ap = argparse.ArgumentParser(description=__doc__.split("\n")[0])
     ap.add_argument("--query", required=True, help="feature pickle of the query/test split")
     ap.add_argument("--support", default=None, help="feature pickle of the support/train split (few-shot)")
     ap.add_argument("--results-root", default=".")
+    ap.add_argument("--config-root", default=None, help="directory with main_config.yaml, datasets_config/, methods_config/ "
+                                                        "(default: ./config if it exists, else the built-in defaults)")
     ap.add_argument("--opts", default=None, nargs=argparse.REMAINDER)
     ns = ap.parse_args(argv)
     opts = ns.opts or []
     if len(opts) % 2:
         ap.error("--opts takes key value pairs")
-    overrides = {opts[i]: _decode(opts[i + 1]) for i in range(0, len(opts), 2)}
-    cfg = CfgNode(MAIN_DEFAULTS)
-    cfg.update(overrides)
-    if cfg.method not in METHOD_DEFAULTS:
-        ap.error(f"method must be one of {sorted(METHOD_DEFAULTS)}")
-    cfg.update(METHOD_DEFAULTS[cfg.method])
-    cfg.update(overrides)                      # command line wins, as in main.py:32-33
+    root = ns.config_root or ("config" if os.path.isfile(os.path.join("config", "main_config.yaml")) else None)
+    if root is not None:
+        cfg = load_merged_config(root, opts)
+        cfg.setdefault("seed", 2020)
+    else:
+        cfg = merge_cfg_from_list(CfgNode(MAIN_DEFAULTS), opts)
+        if cfg.method not in METHOD_DEFAULTS:
+            ap.error(f"method must be one of {sorted(METHOD_DEFAULTS)}")
+        cfg.update(METHOD_DEFAULTS[cfg.method])
+        cfg = merge_cfg_from_list(cfg, opts)           # command line wins, as in main.py:32-33
+    cfg.results_root = ns.results_root
     return ns, cfg
 
 

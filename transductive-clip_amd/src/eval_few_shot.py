@@ -2,6 +2,8 @@
 batched engine; see src/eval_zero_shot.py for the structure.  Per batch the reference draws all
 query index sets first, then all support index sets (eval_few_shot.py:233-241); the same order is
 kept so that a seeded run sees the reference's tasks."""
+import os
+
 import numpy as np
 import torch
 
@@ -50,6 +52,41 @@ class Evaluator_few_shot:
             raise ValueError(f"method {args.name_method!r} is not part of the EM-Dirichlet engine")
         return cls(model=model, device=device, log_file=log_file, args=args)
 
+    # ---- validation-tuned parameter (reference: eval_few_shot.py:130-187)
+    _TUNED = {'LAPLACIAN_SHOT': 'lmd', 'ALPHA_TIM': 'alpha_value', 'PADDLE': 'lambd', 'BDCSPN': 'temp'}
+
+    def set_value_opt_param(self, opt_param):
+        if self.args.name_method in self._TUNED:
+            self.args[self._TUNED[self.args.name_method]] = opt_param
+
+    def set_method_opt_param(self):
+        """Test runs of a tunable method use the parameter that did best on the validation split: the
+        sweep file results_few_shot/val/<dataset>/<METHOD>_<softmax|visual>_s<shots>.txt (imagenet borrows
+        caltech101's, eval_few_shot.py:161-166), rows `param<TAB>acc`, the LAST best row wins.  A missing or
+        unreadable file is an error, as in the reference."""
+        a = self.args
+        word = '_softmax' if a.use_softmax_feature else '_visual'
+        dataset = 'caltech101' if a.dataset == 'imagenet' else a.dataset
+        name_file = os.path.join(getattr(a, 'results_root', '.'), 'results_few_shot', 'val', str(dataset),
+                                 '{}_s{}.txt'.format(a.name_method + word, a.shots))
+        try:
+            params, accs = [], []
+            with open(name_file, 'r') as f:
+                for i, line in enumerate(f):
+                    if i < 2:
+                        continue
+                    cells = line.split('\t')
+                    params.append(float(cells[0]))
+                    accs.append(float(cells[1]))
+            accs = np.array(accs)
+            opt_param = params[int(np.argwhere(accs == np.amax(accs))[-1][0])]
+        except Exception:
+            raise ValueError("The optimal parameter was not found. Please make sure you have performed the "
+                             "tuning of the parameter on the validation set.")
+        self.logger.info('opt param {}'.format(opt_param))
+        self.set_value_opt_param(opt_param)
+        return opt_param
+
     def sample_indices(self, all_labels_support, all_labels_query):
         a = self.args
         q_all, s_all = [], []
@@ -77,6 +114,11 @@ class Evaluator_few_shot:
         Q = q_idx.shape[2]
         mine = sharding.my_batches(n_batches)
         K = tab_q.shape[1]
+        # the parameter tuned on the validation split, when the test split is evaluated (eval_few_shot.py:252-254;
+        # the reference re-reads the file for every batch, the value is the same)
+        if getattr(a, 'used_test_set', 'test') == 'test' and getattr(a, 'tunable', False) \
+                and not getattr(a, 'skip_tuned_param', False):
+            self.set_method_opt_param()
         method = self.get_method_builder(model=model, device=self.device, args=a, log_file=self.log_file)
         timestamps = 0.0
         if mine:

@@ -32,120 +32,98 @@ class EMDirichletResult:
             setattr(self, k, val)
 
 
+class _Call:
+    """One engine call: workspace from PyTorch's caching allocator (256-byte aligned view), output tensors on
+    the inputs' device, the entry point launched on the current stream, the workspace kept alive until that
+    stream has consumed it.  `args(ws_ptr, ws_bytes, stream)` builds the C argument tuple."""
+
+    def __init__(self, dev, problem, ws_query):
+        self.dev, self.p, self.lib = dev, problem, _capi.lib()
+        self.ws_bytes = getattr(self.lib, ws_query)(ctypes.byref(problem))
+        if self.ws_bytes == 0:
+            raise RuntimeError(f"{ws_query} rejected the problem: " + self.lib.tclip_last_error().decode())
+
+    def empty(self, *shape, dtype=torch.float32):
+        return torch.empty(*shape, dtype=dtype, device=self.dev)
+
+    def launch(self, entry, args):
+        with torch.cuda.device(self.dev):
+            ws = torch.empty(self.ws_bytes + 256, dtype=torch.uint8, device=self.dev)
+            off = (-ws.data_ptr()) % 256
+            rc = getattr(self.lib, entry)(ctypes.byref(self.p), *args(ctypes.c_void_p(ws.data_ptr() + off), self.ws_bytes, _stream()))
+            _capi.check(rc, entry)
+            ws.record_stream(torch.cuda.current_stream())
+
+
+def _query(x_q, name="x_q"):
+    _require_cuda(x_q, name)
+    return x_q.contiguous().float()
+
+
+def _support(x_q, x_s, y_s):
+    _require_cuda(x_s, "x_s")
+    _require_cuda(y_s, "y_s")
+    x_s = x_s.contiguous().float()
+    y_s = y_s.reshape(x_s.shape[0], -1).contiguous().long()
+    T, _, K = x_q.shape
+    if x_s.shape[0] != T or x_s.shape[2] != K or y_s.shape != x_s.shape[:2]:
+        raise ValueError("x_s must be (T,S,K) and y_s (T,S) with the T and K of x_q")
+    return x_s, y_s
+
+
 def run_em_dirichlet(x_q, x_s=None, y_s=None, *, n_batches=1, iters, iter_mm=1000, lambd, hard=False):
     """x_q (T,Q,K) f32 cuda with T = n_batches * tasks_per_batch; x_s (T,S,K), y_s (T,S) for few-shot.
 
     Returns EMDirichletResult of cuda tensors; nothing is synchronised."""
-    _require_cuda(x_q, "x_q")
-    x_q = x_q.contiguous().float()
+    x_q = _query(x_q)
     T, Q, K = x_q.shape
     if T % n_batches:
         raise ValueError("number of tasks must be a multiple of n_batches")
-    few = x_s is not None
     S = 0
-    if few:
-        _require_cuda(x_s, "x_s")
-        x_s = x_s.contiguous().float()
-        y_s = y_s.to(x_q.device).long().reshape(T, -1).contiguous()
+    if x_s is not None:
+        x_s, y_s = _support(x_q, x_s, y_s.to(x_q.device))
         S = x_s.shape[1]
-    dev = x_q.device
-    p = _capi.Problem(n_batches, T // n_batches, Q, K, S, iters, iter_mm, int(lambd), int(bool(hard)))
-    lib = _capi.lib()
-    ws_bytes = lib.tclip_workspace_bytes(ctypes.byref(p))
-    if ws_bytes == 0:
-        raise RuntimeError("tclip_workspace_bytes rejected the problem: " + lib.tclip_last_error().decode())
-    with torch.cuda.device(dev):
-        ws = torch.empty(ws_bytes + 256, dtype=torch.uint8, device=dev)
-        off = (-ws.data_ptr()) % 256
-        u = torch.empty(T, Q, K, device=dev)
-        v = torch.empty(T, K, device=dev)
-        alpha = torch.empty(T, K, K, device=dev)
-        preds = torch.empty(T, Q, dtype=torch.int32, device=dev)
-        crit = torch.zeros(n_batches, max(iters, 1), device=dev)[:, :iters].contiguous()
-        mm = torch.zeros(n_batches, max(iters, 1), dtype=torch.int32, device=dev)[:, :iters].contiguous()
-        rc = lib.tclip_em_dirichlet_run(ctypes.byref(p), _ptr(x_q), _ptr(x_s), _ptr(y_s), _ptr(u), _ptr(v), _ptr(alpha),
-                                        _ptr(preds), _ptr(crit), _ptr(mm), ctypes.c_void_p(ws.data_ptr() + off),
-                                        ws_bytes, _stream())
-        _capi.check(rc, "tclip_em_dirichlet_run")
-        # keep the workspace alive until the stream has consumed it
-        ws.record_stream(torch.cuda.current_stream())
+    c = _Call(x_q.device, _capi.Problem(n_batches, T // n_batches, Q, K, S, iters, iter_mm, int(lambd), int(bool(hard))),
+              "tclip_workspace_bytes")
+    u, v, alpha, preds = c.empty(T, Q, K), c.empty(T, K), c.empty(T, K, K), c.empty(T, Q, dtype=torch.int32)
+    crit = torch.zeros(n_batches, max(iters, 1), device=x_q.device)[:, :iters].contiguous()
+    mm = torch.zeros(n_batches, max(iters, 1), dtype=torch.int32, device=x_q.device)[:, :iters].contiguous()
+    c.launch("tclip_em_dirichlet_run", lambda ws, n, st: (_ptr(x_q), _ptr(x_s), _ptr(y_s), _ptr(u), _ptr(v), _ptr(alpha),
+                                                          _ptr(preds), _ptr(crit), _ptr(mm), ws, n, st))
     return EMDirichletResult(u=u, v=v, alpha=alpha, preds=preds, criterions=crit, mm_iters=mm)
 
 
 def run_soft_kmeans(x_q, *, iters, temperature):
     """SOFT_KMEANS: x_q (T,Q,K) f32 cuda -> (u (T,Q,K), w (T,K,K), preds (T,Q) i32), cuda, not synchronised."""
-    _require_cuda(x_q, "x_q")
-    x_q = x_q.contiguous().float()
+    x_q = _query(x_q)
     T, Q, K = x_q.shape
-    dev = x_q.device
-    p = _capi.Problem(1, T, Q, K, 0, iters, 1, 0, 0)
-    lib = _capi.lib()
-    ws_bytes = lib.tclip_soft_kmeans_workspace_bytes(ctypes.byref(p))
-    if ws_bytes == 0:
-        raise RuntimeError("tclip_soft_kmeans_workspace_bytes rejected the problem: " + lib.tclip_last_error().decode())
-    with torch.cuda.device(dev):
-        ws = torch.empty(ws_bytes + 256, dtype=torch.uint8, device=dev)
-        off = (-ws.data_ptr()) % 256
-        u = torch.empty(T, Q, K, device=dev)
-        w = torch.empty(T, K, K, device=dev)
-        preds = torch.empty(T, Q, dtype=torch.int32, device=dev)
-        rc = lib.tclip_soft_kmeans_run(ctypes.byref(p), _ptr(x_q), ctypes.c_float(float(temperature)), _ptr(u), _ptr(w),
-                                       _ptr(preds), ctypes.c_void_p(ws.data_ptr() + off), ws_bytes, _stream())
-        _capi.check(rc, "tclip_soft_kmeans_run")
-        ws.record_stream(torch.cuda.current_stream())
+    c = _Call(x_q.device, _capi.Problem(1, T, Q, K, 0, iters, 1, 0, 0), "tclip_soft_kmeans_workspace_bytes")
+    u, w, preds = c.empty(T, Q, K), c.empty(T, K, K), c.empty(T, Q, dtype=torch.int32)
+    c.launch("tclip_soft_kmeans_run", lambda ws, n, st: (_ptr(x_q), ctypes.c_float(float(temperature)), _ptr(u), _ptr(w),
+                                                         _ptr(preds), ws, n, st))
     return u, w, preds
 
 
 def run_em_gaussian(x_q, *, iters, temperature, lambd):
     """EM_GAUSSIAN: x_q (T,Q,K) f32 cuda -> (u (T,Q,K), v (T,K), w (T,K,K), preds (T,Q) i32), cuda,
     not synchronised."""
-    _require_cuda(x_q, "x_q")
-    x_q = x_q.contiguous().float()
+    x_q = _query(x_q)
     T, Q, K = x_q.shape
-    dev = x_q.device
-    p = _capi.Problem(1, T, Q, K, 0, iters, 1, int(lambd), 0)
-    lib = _capi.lib()
-    ws_bytes = lib.tclip_soft_kmeans_workspace_bytes(ctypes.byref(p))
-    if ws_bytes == 0:
-        raise RuntimeError("tclip_soft_kmeans_workspace_bytes rejected the problem: " + lib.tclip_last_error().decode())
-    with torch.cuda.device(dev):
-        ws = torch.empty(ws_bytes + 256, dtype=torch.uint8, device=dev)
-        off = (-ws.data_ptr()) % 256
-        u = torch.empty(T, Q, K, device=dev)
-        v = torch.empty(T, K, device=dev)
-        w = torch.empty(T, K, K, device=dev)
-        preds = torch.empty(T, Q, dtype=torch.int32, device=dev)
-        rc = lib.tclip_em_gaussian_run(ctypes.byref(p), _ptr(x_q), ctypes.c_float(float(temperature)), _ptr(u), _ptr(v),
-                                       _ptr(w), _ptr(preds), ctypes.c_void_p(ws.data_ptr() + off), ws_bytes, _stream())
-        _capi.check(rc, "tclip_em_gaussian_run")
-        ws.record_stream(torch.cuda.current_stream())
+    c = _Call(x_q.device, _capi.Problem(1, T, Q, K, 0, iters, 1, int(lambd), 0), "tclip_soft_kmeans_workspace_bytes")
+    u, v, w, preds = c.empty(T, Q, K), c.empty(T, K), c.empty(T, K, K), c.empty(T, Q, dtype=torch.int32)
+    c.launch("tclip_em_gaussian_run", lambda ws, n, st: (_ptr(x_q), ctypes.c_float(float(temperature)), _ptr(u), _ptr(v),
+                                                         _ptr(w), _ptr(preds), ws, n, st))
     return u, v, w, preds
 
 
 def run_em_gaussian_cov(x_q, *, iters, lambd):
     """EM_GAUSSIAN_COV: x_q (T,Q,K) f32 cuda -> (u (T,Q,K), v (T,K), w (T,K,K), s (T,K,K), preds (T,Q) i32),
     cuda, not synchronised."""
-    _require_cuda(x_q, "x_q")
-    x_q = x_q.contiguous().float()
+    x_q = _query(x_q)
     T, Q, K = x_q.shape
-    dev = x_q.device
-    p = _capi.Problem(1, T, Q, K, 0, iters, 1, int(lambd), 0)
-    lib = _capi.lib()
-    ws_bytes = lib.tclip_soft_kmeans_workspace_bytes(ctypes.byref(p))
-    if ws_bytes == 0:
-        raise RuntimeError("tclip_soft_kmeans_workspace_bytes rejected the problem: " + lib.tclip_last_error().decode())
-    with torch.cuda.device(dev):
-        ws = torch.empty(ws_bytes + 256, dtype=torch.uint8, device=dev)
-        off = (-ws.data_ptr()) % 256
-        u = torch.empty(T, Q, K, device=dev)
-        v = torch.empty(T, K, device=dev)
-        w = torch.empty(T, K, K, device=dev)
-        s = torch.empty(T, K, K, device=dev)
-        preds = torch.empty(T, Q, dtype=torch.int32, device=dev)
-        rc = lib.tclip_em_gaussian_cov_run(ctypes.byref(p), _ptr(x_q), _ptr(u), _ptr(v), _ptr(w), _ptr(s), _ptr(preds),
-                                           ctypes.c_void_p(ws.data_ptr() + off), ws_bytes, _stream())
-        _capi.check(rc, "tclip_em_gaussian_cov_run")
-        ws.record_stream(torch.cuda.current_stream())
+    c = _Call(x_q.device, _capi.Problem(1, T, Q, K, 0, iters, 1, int(lambd), 0), "tclip_soft_kmeans_workspace_bytes")
+    u, v, w, s, preds = c.empty(T, Q, K), c.empty(T, K), c.empty(T, K, K), c.empty(T, K, K), c.empty(T, Q, dtype=torch.int32)
+    c.launch("tclip_em_gaussian_cov_run", lambda ws, n, st: (_ptr(x_q), _ptr(u), _ptr(v), _ptr(w), _ptr(s), _ptr(preds), ws, n, st))
     return u, v, w, s, preds
 
 
@@ -157,61 +135,26 @@ def run_kl_kmeans(x_q, *, iters, n_batches=1):
 def run_hard_kmeans(x_q, *, iters, n_batches=1, _entry="tclip_hard_kmeans_run"):
     """HARD_KMEANS: x_q (T,Q,K) f32 cuda -> (u one-hot (T,Q,K), w (T,K,K), preds (T,Q) i32,
     criterions (n_batches, iters)), cuda, not synchronised."""
-    _require_cuda(x_q, "x_q")
-    x_q = x_q.contiguous().float()
+    x_q = _query(x_q)
     T, Q, K = x_q.shape
     if T % n_batches:
         raise ValueError("the number of tasks must be a multiple of n_batches")
-    dev = x_q.device
-    p = _capi.Problem(n_batches, T // n_batches, Q, K, 0, iters, 1, 0, 0)
-    lib = _capi.lib()
-    ws_bytes = lib.tclip_hard_kmeans_workspace_bytes(ctypes.byref(p))
-    if ws_bytes == 0:
-        raise RuntimeError("tclip_hard_kmeans_workspace_bytes rejected the problem: " + lib.tclip_last_error().decode())
-    with torch.cuda.device(dev):
-        ws = torch.empty(ws_bytes + 256, dtype=torch.uint8, device=dev)
-        off = (-ws.data_ptr()) % 256
-        u = torch.empty(T, Q, K, device=dev)
-        w = torch.empty(T, K, K, device=dev)
-        preds = torch.empty(T, Q, dtype=torch.int32, device=dev)
-        crit = torch.empty(n_batches, iters, device=dev)
-        rc = getattr(lib, _entry)(ctypes.byref(p), _ptr(x_q), _ptr(u), _ptr(w), _ptr(preds), _ptr(crit),
-                                  ctypes.c_void_p(ws.data_ptr() + off), ws_bytes, _stream())
-        _capi.check(rc, _entry)
-        ws.record_stream(torch.cuda.current_stream())
+    c = _Call(x_q.device, _capi.Problem(n_batches, T // n_batches, Q, K, 0, iters, 1, 0, 0), "tclip_hard_kmeans_workspace_bytes")
+    u, w, preds, crit = c.empty(T, Q, K), c.empty(T, K, K), c.empty(T, Q, dtype=torch.int32), c.empty(n_batches, iters)
+    c.launch(_entry, lambda ws, n, st: (_ptr(x_q), _ptr(u), _ptr(w), _ptr(preds), _ptr(crit), ws, n, st))
     return u, w, preds, crit
 
 
 def run_paddle(x_q, x_s, y_s, *, iters, lambd):
     """PADDLE: x_q (T,Q,K), x_s (T,S,K) f32 cuda, y_s (T,S) int64 cuda ->
     (u (T,Q,K), v (T,K), w (T,K,K), preds (T,Q) i32), cuda, not synchronised."""
-    _require_cuda(x_q, "x_q")
-    _require_cuda(x_s, "x_s")
-    _require_cuda(y_s, "y_s")
-    x_q, x_s = x_q.contiguous().float(), x_s.contiguous().float()
-    y_s = y_s.reshape(x_s.shape[0], -1).contiguous().long()
+    x_q = _query(x_q)
+    x_s, y_s = _support(x_q, x_s, y_s)
     T, Q, K = x_q.shape
-    S = x_s.shape[1]
-    if x_s.shape != (T, S, K) or y_s.shape != (T, S):
-        raise ValueError("x_s must be (T,S,K) and y_s (T,S) with the T and K of x_q")
-    dev = x_q.device
-    p = _capi.Problem(1, T, Q, K, S, iters, 1, 0, 0)
-    lib = _capi.lib()
-    ws_bytes = lib.tclip_paddle_workspace_bytes(ctypes.byref(p))
-    if ws_bytes == 0:
-        raise RuntimeError("tclip_paddle_workspace_bytes rejected the problem: " + lib.tclip_last_error().decode())
-    with torch.cuda.device(dev):
-        ws = torch.empty(ws_bytes + 256, dtype=torch.uint8, device=dev)
-        off = (-ws.data_ptr()) % 256
-        u = torch.empty(T, Q, K, device=dev)
-        v = torch.empty(T, K, device=dev)
-        w = torch.empty(T, K, K, device=dev)
-        preds = torch.empty(T, Q, dtype=torch.int32, device=dev)
-        rc = lib.tclip_paddle_run(ctypes.byref(p), _ptr(x_q), _ptr(x_s), _ptr(y_s), ctypes.c_float(float(lambd)),
-                                  _ptr(u), _ptr(v), _ptr(w), _ptr(preds), ctypes.c_void_p(ws.data_ptr() + off),
-                                  ws_bytes, _stream())
-        _capi.check(rc, "tclip_paddle_run")
-        ws.record_stream(torch.cuda.current_stream())
+    c = _Call(x_q.device, _capi.Problem(1, T, Q, K, x_s.shape[1], iters, 1, 0, 0), "tclip_paddle_workspace_bytes")
+    u, v, w, preds = c.empty(T, Q, K), c.empty(T, K), c.empty(T, K, K), c.empty(T, Q, dtype=torch.int32)
+    c.launch("tclip_paddle_run", lambda ws, n, st: (_ptr(x_q), _ptr(x_s), _ptr(y_s), ctypes.c_float(float(lambd)), _ptr(u),
+                                                    _ptr(v), _ptr(w), _ptr(preds), ws, n, st))
     return u, v, w, preds
 
 
@@ -234,34 +177,16 @@ NORM_TYPES = {"UN": 0, "L2N": 1, "CL2N": 2}
 def run_bdcspn(x_q, x_s, y_s, *, temp, norm_type="L2N"):
     """BD-CSPN: x_q (T,Q,K), x_s (T,S,K) f32 cuda, y_s (T,S) int64 cuda ->
     (prototypes (T,K,K), u (T,Q,K), preds (T,Q) i32), cuda, not synchronised."""
-    _require_cuda(x_q, "x_q")
-    _require_cuda(x_s, "x_s")
-    _require_cuda(y_s, "y_s")
     if norm_type not in NORM_TYPES:
         raise ValueError(f"norm_type must be one of {sorted(NORM_TYPES)}")
-    x_q, x_s = x_q.contiguous().float(), x_s.contiguous().float()
-    y_s = y_s.reshape(x_s.shape[0], -1).contiguous().long()
+    x_q = _query(x_q)
+    x_s, y_s = _support(x_q, x_s, y_s)
     T, Q, K = x_q.shape
-    S = x_s.shape[1]
-    if x_s.shape != (T, S, K) or y_s.shape != (T, S):
-        raise ValueError("x_s must be (T,S,K) and y_s (T,S) with the T and K of x_q")
-    dev = x_q.device
-    p = _capi.Problem(1, T, Q, K, S, 1, 1, 0, 0)
-    lib = _capi.lib()
-    ws_bytes = lib.tclip_bdcspn_workspace_bytes(ctypes.byref(p))
-    if ws_bytes == 0:
-        raise RuntimeError("tclip_bdcspn_workspace_bytes rejected the problem: " + lib.tclip_last_error().decode())
-    with torch.cuda.device(dev):
-        ws = torch.empty(ws_bytes + 256, dtype=torch.uint8, device=dev)
-        off = (-ws.data_ptr()) % 256
-        prototypes = torch.empty(T, K, K, device=dev)
-        u = torch.empty(T, Q, K, device=dev)
-        preds = torch.empty(T, Q, dtype=torch.int32, device=dev)
-        rc = lib.tclip_bdcspn_run(ctypes.byref(p), _ptr(x_q), _ptr(x_s), _ptr(y_s), ctypes.c_float(float(temp)),
-                                  ctypes.c_int32(NORM_TYPES[norm_type]), _ptr(prototypes), _ptr(u), _ptr(preds),
-                                  ctypes.c_void_p(ws.data_ptr() + off), ws_bytes, _stream())
-        _capi.check(rc, "tclip_bdcspn_run")
-        ws.record_stream(torch.cuda.current_stream())
+    c = _Call(x_q.device, _capi.Problem(1, T, Q, K, x_s.shape[1], 1, 1, 0, 0), "tclip_bdcspn_workspace_bytes")
+    prototypes, u, preds = c.empty(T, K, K), c.empty(T, Q, K), c.empty(T, Q, dtype=torch.int32)
+    c.launch("tclip_bdcspn_run", lambda ws, n, st: (_ptr(x_q), _ptr(x_s), _ptr(y_s), ctypes.c_float(float(temp)),
+                                                    ctypes.c_int32(NORM_TYPES[norm_type]), _ptr(prototypes), _ptr(u),
+                                                    _ptr(preds), ws, n, st))
     return prototypes, u, preds
 
 

@@ -31,13 +31,15 @@ def gather_batch_results(local, n_batches, rank=None, world_size=None):
     if world_size == 1:
         return local
     per_rank = (n_batches + world_size - 1) // world_size
-    pad = torch.zeros((per_rank,) + tuple(local.shape[1:]), dtype=local.dtype, device=local.device)
-    pad[: local.shape[0]] = local
+    # RCCL gathers device tensors; under gloo (CPU tests, or ranks that share one GPU) the blocks travel through the host
+    where = local.device if dist.get_backend() == "nccl" else torch.device("cpu")
+    pad = torch.zeros((per_rank,) + tuple(local.shape[1:]), dtype=local.dtype, device=where)
+    pad[: local.shape[0]] = local.to(where)
     blocks = [torch.empty_like(pad) for _ in range(world_size)]
     dist.all_gather(blocks, pad)
     if rank != 0:
         return None
-    out = torch.empty((n_batches,) + tuple(local.shape[1:]), dtype=local.dtype, device=local.device)
+    out = torch.empty((n_batches,) + tuple(local.shape[1:]), dtype=local.dtype, device=where)
     for r in range(world_size):
         ids = my_batches(n_batches, r, world_size)
         if ids:
