@@ -30,14 +30,20 @@ Extra objects on the JSON line:
   secondary    the K=100 workload of round 1 (BASELINE configs[1]), a few steps, same roofline fields.
   cpu_baseline the torch-eager CPU restatement of the reference loop (oracle/ref_torch.py, kind
                "port") on this host: K=1000 is ~6 minutes per task on 8 cores, so, as SURVEY.md 8d
-               prescribes, 51 and 151 MM iterations plus one M/E-step are timed on a 2-task batch
-               and extrapolated over the MM schedule the GPU run recorded.
+               prescribes, MM iterations of the first and of a later outer iteration plus one M/E-step are timed
+               on a 2-task batch and extrapolated over the MM schedule the GPU run recorded.
 """
 import argparse
 import json
 import os
 import sys
 import time
+
+# Independent batches run on up to three HIP streams; HIP gives a process four hardware queues by default and RCCL's
+# own streams take some of them under torch.distributed, after which the engine's streams share a queue and
+# serialise (measured with one rank under torch.distributed.run: K=100 1 641 tasks/s against 2 119 with 8 queues,
+# which is also the rate without a process group).  Read when the HIP runtime initialises, so set before torch.
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
@@ -69,9 +75,11 @@ from tclip_amd import synth
 torch.set_num_threads({threads})
 x_q, _ = synth.make_query_tasks({n_tasks}, {K}, seed=0)
 out = {{}}
-for mm in {mm_list}:
-    r = ref_torch.run(x_q, n_class={K}, iters={iters}, iter_mm=mm, lambd={lambd}, hard=False)
-    out[str(mm)] = r["seconds"]
+if {warm}:
+    ref_torch.run(x_q, n_class={K}, iters=1, iter_mm=2, lambd={lambd}, hard=False)      # thread pool, allocator
+for iters, mm in {mm_list}:
+    r = ref_torch.run(x_q, n_class={K}, iters=iters, iter_mm=mm, lambd={lambd}, hard=False)
+    out[str(iters) + "x" + str(mm)] = r["seconds"]
 print(json.dumps({{"seconds": out, "threads": torch.get_num_threads(), "torch": torch.__version__}}))
 """
 
@@ -87,12 +95,12 @@ def cpu_baseline(w, mm_schedule, budget_s=300):
         usable = os.cpu_count() or 1
     threads = max(1, min(usable, 16))
     K = w["K"]
-    if K >= 397:          # extrapolated: one outer iteration with 51 and with 151 MM iterations
-        n_tasks, iters, mm_list = 2, 1, [51, 151]
+    if K >= 397:          # extrapolated from one and two outer iterations with 101 and with 301 MM iterations each
+        n_tasks, mm_list = 2, [(1, 101), (1, 301), (2, 101), (2, 301)]
     else:                 # affordable in full: one whole batch, whole schedule
-        n_tasks, iters, mm_list = w["tasks_per_batch"], ITERS, [ITER_MM]
-    code = _CPU_SNIPPET.format(root=ROOT, threads=threads, n_tasks=n_tasks, K=K, iters=iters, mm_list=mm_list,
-                               lambd=int(K / 5) * N_QUERY)
+        n_tasks, mm_list = w["tasks_per_batch"], [(ITERS, ITER_MM)]
+    code = _CPU_SNIPPET.format(root=ROOT, threads=threads, n_tasks=n_tasks, K=K, mm_list=mm_list,
+                               lambd=int(K / 5) * N_QUERY, warm=len(mm_list) > 1)
     try:
         out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=budget_s)
         info = json.loads(out.stdout.strip().splitlines()[-1])
@@ -101,19 +109,23 @@ def cpu_baseline(w, mm_schedule, budget_s=300):
                 "sample": f"not measured: {type(e).__name__} within {budget_s}s budget"}
     secs = info["seconds"]
     if len(mm_list) == 1:
-        total = secs[str(ITER_MM)]
+        total = secs[f"{ITERS}x{ITER_MM}"]
         return {"value": n_tasks / total, "unit": "tasks/s", "cores": info["threads"], "kind": "port",
                 "sample": f"{n_tasks} tasks (one batch) of the same K={K}, 75-query workload, full {ITERS}x{ITER_MM} "
                           f"schedule, torch {info['torch']} CPU eager, {total:.1f}s"}
-    t51, t151 = secs["51"], secs["151"]
-    per_mm = (t151 - t51) / 100.0                   # one MM iteration of the n_tasks batch
-    per_me = max(t51 - 51 * per_mm, 0.0)            # M-step statistics + E-step + criterion of one outer iteration
-    total = sum(per_me + n * per_mm for n in mm_schedule)
+    # an MM iteration costs differently in the first outer iteration (every class alive, alpha near 1) and in the
+    # later ones (few live classes, large alpha), so both regimes are timed: all for the n_tasks batch
+    a1, b1, a2, b2 = secs["1x101"], secs["1x301"], secs["2x101"], secs["2x301"]
+    mm_first = (b1 - a1) / 200.0                                   # one MM iteration, first outer iteration
+    mm_later = max((b2 - a2) / 200.0 - mm_first, 0.0)              # one MM iteration, second outer iteration
+    per_me = max(a1 - 101 * mm_first, 0.0)                         # M-step statistics + E-step + criterion, once per outer iteration
+    total = len(mm_schedule) * per_me + mm_schedule[0] * mm_first + sum(mm_schedule[1:]) * mm_later
     return {"value": n_tasks / total, "unit": "tasks/s", "cores": info["threads"], "kind": "port",
-            "sample": f"{n_tasks}-task batch of the same K={K}, 75-query workload: one outer iteration timed with 51 "
-                      f"({t51:.1f}s) and 151 ({t151:.1f}s) MM iterations -> {1e3 * per_mm:.1f} ms per MM iteration, "
-                      f"{per_me:.2f}s per M/E-step, extrapolated over the recorded schedule of "
-                      f"{int(sum(mm_schedule))} MM iterations in {len(mm_schedule)} outer iterations = {total:.0f}s "
+            "sample": f"{n_tasks}-task batch of the same K={K}, 75-query workload, timed: 1 outer iteration with 101 ({a1:.1f}s) and "
+                      f"301 ({b1:.1f}s) MM iterations, 2 outer iterations with 101 ({a2:.1f}s) and 301 ({b2:.1f}s) -> "
+                      f"{1e3 * mm_first:.1f} / {1e3 * mm_later:.1f} ms per MM iteration in the first / a later outer iteration, "
+                      f"{per_me:.2f}s per M/E-step; extrapolated over the recorded schedule ({mm_schedule[0]} + "
+                      f"{int(sum(mm_schedule[1:]))} MM iterations in {len(mm_schedule)} outer iterations) = {total:.0f}s "
                       f"(SURVEY.md 8d); torch {info['torch']} CPU eager",
             "extrapolated": True}
 

@@ -91,6 +91,9 @@ SMALL = {
     "zs_hkm_K37_N6": ("zs_hkm", 37, 6, 20, 0, 2021, True),
     "zs_hkm_K100_N4": ("zs_hkm", 100, 4, 20, 0, 2022, True),
     "zs_hkm_K397_N2": ("zs_hkm", 397, 2, 20, 0, 2023, True),
+    # found by tests/golden/find_borderline.py: a stop test of these runs lands within 1e-4 (relative) of the 1e-11 threshold
+    "zs_soft_K8_N2_borderline": ("zs_soft", 8, 2, 20, 0, 6087, True),
+    "zs_soft_K5_N2_borderline": ("zs_soft", 5, 2, 20, 0, 5574, True),
     # fewer than 8 classes: ATen's scalar reduction paths (scalar_inner_sum, scalar_outer_sum)
     "zs_soft_K7_N4": ("zs_soft", 7, 4, 20, 0, 2030, True),
     "zs_soft_K2_N4": ("zs_soft", 2, 4, 20, 0, 2031, True),

@@ -118,7 +118,10 @@ def test_stop_test_decisions_have_margin(name):
         crit = (st[:, :, 0] ** 2) / (st[:, :, 1] ** 2)         # the reference's own fp32 arithmetic
     seen = ~np.isnan(crit)
     margin = np.abs(crit[seen].astype(np.float64) / 1e-11 - 1.0)
-    assert margin.min() > 1e-4, f"a recorded stop test sits within {margin.min():.1e} of the threshold"
+    if "borderline" in name:      # picked by tests/golden/find_borderline.py: a decision 5e-5 / 8e-5 from the threshold,
+        assert 2e-6 < margin.min() < 1e-4, margin.min()      # close, yet outside the band where fp64 and fp32 sums can disagree
+    else:
+        assert margin.min() > 1e-4, f"a recorded stop test sits within {margin.min():.1e} of the threshold"
     # the recorded decisions are consistent with the recorded MM counts ...
     for i, n_mm in enumerate(g["mm_iters"].tolist()):
         k = int(seen[i].sum())                                  # checkpoints evaluated in outer iteration i

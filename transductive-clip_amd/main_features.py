@@ -25,6 +25,8 @@ import sys
 import numpy as np
 import torch
 
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")    # see tclip_amd/__init__.py: the engine's streams need their own hardware queues
+
 HERE = os.path.dirname(os.path.abspath(__file__))
 if HERE not in sys.path:
     sys.path.insert(0, HERE)
