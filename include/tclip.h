@@ -91,6 +91,12 @@ int tclip_match_clusters_host(int32_t n_task, int32_t n_query, int32_t n_class, 
                               const int32_t* n_clusters, const int32_t* cluster_ids,
                               const float* prototypes, const int64_t* y_q, int32_t graph_matching,
                               int32_t* new_preds, float* acc);
+/* The same with an explicit row count per task of cluster_ids / prototypes ([T, c_stride] / [T, c_stride, K]
+ * instead of Cmax): lets the caller copy to the host only as many prototype rows as the fullest task uses. */
+int tclip_match_clusters_host_strided(int32_t n_task, int32_t n_query, int32_t n_class, const int32_t* preds,
+                                      const int32_t* n_clusters, const int32_t* cluster_ids, const float* prototypes,
+                                      const int64_t* y_q, int32_t graph_matching, int32_t c_stride, int32_t* new_preds,
+                                      float* acc);
 
 /* Task construction for the task-batch loop (eval_zero_shot.py:160-168): gathers rows of a
  * device-resident feature table.  table device [n_rows, K] f32, idx device [n_out] i64,
@@ -199,10 +205,9 @@ int tclip_profile_collect(double* mm_busy_ms, double* mm_launch_ms_sum, int64_t*
  * restores the default.  Process-wide; results do not depend on it. */
 int tclip_debug_set_probe_chunks(int32_t chunks);
 
-/* Live rows of short rows (n_class <= 256) advance two per 32-lane group (16 rows per block) when
- * the row list of a launch holds at least `rows` rows (default rule: enough to fill the machine),
- * one per group otherwise.  For tests: 0 forces the two-row kernel, a huge value the one-row
- * kernel, negative restores the default.  Process-wide; results do not depend on it. */
+/* Rows of up to 256 elements are spread over 16 lanes in the MM kernels (4 rows per wavefront), longer ones
+ * over 32.  For tests: 0 forces the 32-lane layout for every row length, negative restores the default rule.
+ * Process-wide; results do not depend on it. */
 int tclip_debug_set_rowset_min_rows(int32_t rows);
 
 /* Device self-test (used by tests/test_gpu_primitives.py).  out host [14]:

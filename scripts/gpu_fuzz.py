@@ -12,7 +12,7 @@ import torch
 from oracle import c_oracle
 from tclip_amd import engine, synth
 
-if "TCLIP_FUZZ_ROWSET_MIN_ROWS" in os.environ:      # 0: force the two-rows-per-group live kernel on these small problems
+if "TCLIP_FUZZ_ROWSET_MIN_ROWS" in os.environ:      # 0: force the 32-lanes-per-row layout of the MM kernels
     engine.debug_set_rowset_min_rows(int(os.environ["TCLIP_FUZZ_ROWSET_MIN_ROWS"]))
 n_cases = int(sys.argv[1]) if len(sys.argv) > 1 else 40
 rng = random.Random(int(sys.argv[2]) if len(sys.argv) > 2 else 1)

@@ -9,6 +9,8 @@ B = int(sys.argv[2]) if len(sys.argv) > 2 else 10
 N = int(sys.argv[3]) if len(sys.argv) > 3 else 100
 iters = int(sys.argv[4]) if len(sys.argv) > 4 else 3
 hard = bool(int(sys.argv[5])) if len(sys.argv) > 5 else False
+if os.environ.get('TCLIP_WIDE'):
+    engine.debug_set_rowset_min_rows(0)          # 32 lanes per row for every K (test hook)
 x_q, y_q = synth.make_query_tasks(B * N, K, seed=3)
 x_q = x_q.cuda()
 for rep in range(2):

@@ -89,11 +89,13 @@ def test_limit_cycle_shortcut_is_exact(K, N, B):
         assert torch.equal(r.alpha, runs[0].alpha) and torch.equal(r.u, runs[0].u)
 
 
-@pytest.mark.parametrize("K,N,B,hard", [(10, 7, 3, False), (37, 5, 2, True), (100, 6, 2, False), (200, 3, 1, False), (33, 4, 2, False)])
-def test_two_rows_per_lane_group_is_exact(K, N, B, hard):
-    """Large row lists run the live rows two per 32-lane group (16 rows per block share the barriers
-    and the dense lgamma passes); small ones, one per group.  Forced either way on the same small
-    problem (ragged row counts, several batches, a few-shot case) the bits must not change."""
+@pytest.mark.parametrize("K,N,B,hard", [(2, 5, 2, False), (7, 6, 2, False), (10, 7, 3, False), (37, 5, 2, True), (47, 4, 2, False),
+                                        (64, 3, 2, False), (65, 3, 2, True), (100, 6, 2, False), (102, 4, 1, False), (128, 3, 1, False),
+                                        (129, 3, 1, False), (196, 3, 1, False), (200, 3, 1, False), (256, 2, 1, False), (33, 4, 2, False)])
+def test_lane_layouts_are_equivalent(K, N, B, hard):
+    """Short rows are spread over 8 or 16 lanes instead of 32 (several rows per wavefront, fuller lanes); the
+    row sum keeps torch's association order in every layout.  The default layout and the forced 32-lane layout
+    must give the same bits on the same problem (ragged row counts, several batches, a few-shot case)."""
     from tclip_amd import engine, synth
     x_q, _ = synth.make_query_tasks(B * N, K, seed=70 + K)
     x = x_q.cuda()
@@ -104,9 +106,9 @@ def test_two_rows_per_lane_group_is_exact(K, N, B, hard):
         xs, ys = xs.cuda(), ys.squeeze(2).cuda()
     runs = []
     try:
-        for min_rows in (2 ** 30, 0, 0):
-            engine.debug_set_rowset_min_rows(min_rows)
-            r = engine.run_em_dirichlet(x, xs, ys, n_batches=B, iters=4, iter_mm=230, lambd=int(K / 5) * 75, hard=hard)
+        for wide in (-1, 0, -1):
+            engine.debug_set_rowset_min_rows(wide)
+            r = engine.run_em_dirichlet(x, xs, ys, n_batches=B, iters=4, iter_mm=230, lambd=max(1, int(K / 5)) * 75, hard=hard)
             torch.cuda.synchronize()
             runs.append(r)
     finally:
@@ -130,7 +132,7 @@ def test_nan_in_one_task_leaves_the_others_exact(K, N):
     x_q[1, 5, 3] = float("nan")
     res = engine.run_em_dirichlet(x_q.cuda(), n_batches=1, iters=iters, iter_mm=iter_mm, lambd=lambd, hard=False)
     torch.cuda.synchronize()
-    try:        # the same through the two-rows-per-group kernel (its generic path loops over both rows)
+    try:        # the same through the 32-lanes-per-row layout
         engine.debug_set_rowset_min_rows(0)
         res2 = engine.run_em_dirichlet(x_q.cuda(), n_batches=1, iters=iters, iter_mm=iter_mm, lambd=lambd, hard=False)
         torch.cuda.synchronize()

@@ -73,6 +73,76 @@ __device__ __forceinline__ float group_sum_torch(const float (&x)[E], int K, int
     return fin;
 }
 
+// The same sum with a row spread over G = 8 or 16 lanes (short rows: more rows per wavefront, fuller lanes).
+// Element d lives in register d / G of lane d % G.  With H = G / 8 lanes-of-eight per group, lane (h, j) =
+// 8 h + j holds the 8-float vector v = e H + h in register e; torch's accumulator r = v % 4 and step m = v / 4
+// are r = (e % P) H + h, m = e / P with P = 4 / H registers per step, so a lane keeps P partial sums.
+template <int E, int G>
+__device__ __forceinline__ float group_sum_torch_g(const float (&x)[E], int K, int lane) {
+    static_assert(G == 8 || G == 16, "lanes per row");
+    constexpr int H = G / 8, P = 4 / H;
+    static_assert((E + P - 1) / P <= 31, "rows this long need the second cascade dump of the 32-lane form");
+    auto shfl = [](float v, int src) { return __shfl(v, src, G); };
+    if (K < 8) {  // scalar_inner_sum: 4 interleaved scalar accumulators; the whole row sits in register 0
+        const int size_ilp = K >> 2;
+        float fin = size_ilp ? shfl(x[0], 0) : 0.0f;
+        for (int i = size_ilp * 4; i < K; i++) fin += shfl(x[0], i);
+        if (size_ilp) {
+            fin += shfl(x[0], 1);
+            fin += shfl(x[0], 2);
+            fin += shfl(x[0], 3);
+        }
+        return fin;
+    }
+    const int vec_size = K >> 3, size_ilp = vec_size >> 2;
+    const int j = lane & 7;
+    float a0[P], a1[P], rag[P];
+#pragma unroll
+    for (int p = 0; p < P; p++) a0[p] = a1[p] = rag[p] = 0.0f;
+#pragma unroll
+    for (int e = 0; e < E; e++) {
+        const int p = e % P, m = e / P;                     // compile-time
+        if (p == 0 && m == 16 && size_ilp >= 16) {          // 16-step cascade dump (rows of 512+ elements only)
+#pragma unroll
+            for (int q = 0; q < P; q++) { a1[q] += a0[q]; a0[q] = 0.0f; }
+        }
+        if (m < size_ilp) a0[p] += x[e];
+        if (m == size_ilp) rag[p] = x[e];
+    }
+    float pm[P];
+#pragma unroll
+    for (int p = 0; p < P; p++) pm[p] = a0[p] + a1[p];
+    // accumulator 0 first, then the whole vectors beyond the 4-way part (vector 4 size_ilp + i sits in
+    // register-of-step i / H of lane-of-eight i % H), then accumulators 1, 2, 3
+    const int nleft = vec_size - 4 * size_ilp;              // 0..3
+    float p0 = pm[0];
+#pragma unroll
+    for (int i = 0; i < 3; i++) {
+        const float v = shfl(rag[i / H], 8 * (i % H) + j);
+        if (i < nleft) p0 += v;
+    }
+#pragma unroll
+    for (int r = 1; r < 4; r++) p0 += shfl(pm[r / H], 8 * (r % H) + j);      // valid in lanes 0..7
+    // scalar tail (K mod 8 elements, in the partial vector vec_size) first, then the 8 vector lanes in order
+    const int ntail = K - 8 * vec_size, tv = vec_size & 3;   // the partial vector is vector tv of the ragged step
+    float fin = 0.0f;
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+        if (i == tv)                                         // wave-uniform
+            for (int t = 0; t < ntail; t++) fin += shfl(rag[i / H], 8 * (i % H) + t);
+    }
+#pragma unroll
+    for (int t = 0; t < 8; t++) fin += shfl(p0, t);
+    return fin;
+}
+
+template <int G>
+__device__ __forceinline__ double group_sum_f64_g(double v) {
+#pragma unroll
+    for (int m = G / 2; m >= 1; m >>= 1) v += __shfl_xor(v, m, G);
+    return v;
+}
+
 // fp64 sum over the 32 lanes of a group (fixed butterfly order, same value in every lane).
 __device__ __forceinline__ double group_sum_f64(double v) {
 #pragma unroll

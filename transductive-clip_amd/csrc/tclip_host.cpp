@@ -78,9 +78,18 @@ extern "C" int tclip_match_clusters_host(int32_t T, int32_t Q, int32_t K, const 
                                          const int32_t* n_clusters, const int32_t* cluster_ids,
                                          const float* prototypes, const int64_t* y_q, int32_t graph_matching,
                                          int32_t* new_preds, float* acc) {
+    return tclip_match_clusters_host_strided(T, Q, K, preds, n_clusters, cluster_ids, prototypes, y_q, graph_matching,
+                                             Q < K ? Q : K, new_preds, acc);
+}
+
+extern "C" int tclip_match_clusters_host_strided(int32_t T, int32_t Q, int32_t K, const int32_t* preds,
+                                                 const int32_t* n_clusters, const int32_t* cluster_ids,
+                                                 const float* prototypes, const int64_t* y_q, int32_t graph_matching,
+                                                 int32_t c_stride, int32_t* new_preds, float* acc) {
     if (T < 1 || Q < 1 || K < 2 || !preds || !n_clusters || !cluster_ids || !prototypes || !y_q || !new_preds || !acc)
         return TCLIP_ERR_ARG;
-    const int Cmax = Q < K ? Q : K;
+    const int Cmax = c_stride;
+    if (Cmax < 1 || Cmax > (Q < K ? Q : K)) return TCLIP_ERR_ARG;
     std::vector<double> cost;
     std::vector<int> col_of_row, lut(K);
     for (int t = 0; t < T; t++) {

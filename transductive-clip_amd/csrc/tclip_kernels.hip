@@ -384,18 +384,18 @@ struct MMArgs {
 #ifndef TCLIP_Y_REGS_MAX_E
 #define TCLIP_Y_REGS_MAX_E 16
 #endif
-template <int E>
+template <int E, int G = kGroup>
 struct RowY {
     static constexpr bool kInRegs = E <= TCLIP_Y_REGS_MAX_E;
     float r[kInRegs ? E : 1];
     const float* g;      // row base in global memory, or nullptr for a dead row (y = -10)
     int lane, K, n_full; // n_full = K / 32: registers below it lie entirely inside the row (wave-uniform)
     __device__ __forceinline__ void load(const float* row_y, int lane_, int K_) {
-        g = row_y; lane = lane_; K = K_; n_full = K_ / kGroup;
+        g = row_y; lane = lane_; K = K_; n_full = K_ / G;
         if (kInRegs) {
 #pragma unroll
             for (int e = 0; e < (kInRegs ? E : 1); e++) {
-                const int d = e * kGroup + lane;
+                const int d = e * G + lane;
                 r[e] = d < K ? (g ? g[d] : -10.0f) : 0.0f;
             }
         }
@@ -403,7 +403,7 @@ struct RowY {
     __device__ __forceinline__ float get(int e) const {
         if (kInRegs) return r[kInRegs ? e : 0];
         if (!g) return -10.0f;                       // dead rows: y is not read by lanes beyond the row either
-        const int d = e * kGroup + lane;
+        const int d = e * G + lane;
         if (e < n_full) return g[d];                 // uniform branch: no lane mask on the load
         return d < K ? g[d] : 0.0f;
     }
@@ -431,11 +431,11 @@ __device__ __forceinline__ float lgamma_big_dense(float v) {
 #ifndef TCLIP_MM_PACKED
 #define TCLIP_MM_PACKED 1
 #endif
-template <int E>
-__device__ __forceinline__ void mm_apply_updates(float (&beta)[E], const RowY<E>& yv, int K, int lane, float psi_s,
+template <int E, int G = kGroup>
+__device__ __forceinline__ void mm_apply_updates(float (&beta)[E], const RowY<E, G>& yv, int K, int lane, float psi_s,
                                                  const LogTabEntry* tab, const float* queue, int base, bool measure,
                                                  double& num, double& den) {
-    const int n_full = K / kGroup;                 // registers below it hold 32 elements of the row (wave-uniform)
+    const int n_full = K / G;                      // registers below it hold G elements of the row (wave-uniform)
 #pragma unroll
     for (int p = 0; p < (TCLIP_MM_PACKED ? E / 2 : 0); p++) {
         const int e = 2 * p;
@@ -449,7 +449,7 @@ __device__ __forceinline__ void mm_apply_updates(float (&beta)[E], const RowY<E>
         base += __popcll(m1);
         const f2 nb = pk_mm_update(a, f2{yv.get(e), yv.get(e + 1)}, pk(psi_s), f2{lg0, lg1}, tab);
         const bool full = e + 1 < n_full;
-        const bool ok0 = full || e * kGroup + lane < K, ok1 = full || (e + 1) * kGroup + lane < K;
+        const bool ok0 = full || e * G + lane < K, ok1 = full || (e + 1) * G + lane < K;
         if (measure) {
             const double d0 = (double)nb.x - (double)a.x, d1 = (double)nb.y - (double)a.y;
             if (ok0) { num += d0 * d0; den += (double)a.x * (double)a.x; }
@@ -476,7 +476,7 @@ __device__ __forceinline__ void mm_apply_updates(float (&beta)[E], const RowY<E>
         if (__builtin_expect(__builtin_amdgcn_ballot_w64(!sure) != 0ull, 0)) lg_small = sure ? lg_small : lgamma_sleef_05_23(big ? 2.0f : x1);
         const float psi1 = digamma_xp1(a, tab);
         const float nb = mm_update_algebra(a, yv.get(e), psi_s, psi1, big ? lg_big : lg_small);
-        const bool ok = e * kGroup + lane < K;
+        const bool ok = e * G + lane < K;
         if (measure && ok) {
             const double df = (double)nb - (double)a;
             num += df * df;
@@ -633,12 +633,19 @@ __global__ __launch_bounds__(256, (E > 8 ? TCLIP_MM_WAVES_LARGE : TCLIP_MM_WAVES
 // `rowsum` / `psi`: the row sums of the block's rows and digamma of them, double-buffered like the counts:
 // one wave evaluates digamma for all rows of the block in a single pass (one row per lane) inside the
 // dense-pass window instead of every 32-lane group evaluating its own row's value 32 times over.
-struct QueueCtl { int count[2][8]; int bad; float rowsum[2][32]; float psi[2][32]; };
+struct QueueCtl { int count[2][8]; int bad; float rowsum[2][64]; float psi[2][64]; };
 
-template <int E, int W, int R>
-__device__ __forceinline__ void mm_iterate_block(float (&beta)[R][E], const RowY<E> (&yv)[R], int K, int lane,
+template <int E, int G>
+__device__ __forceinline__ float row_sum_torch(const float (&x)[E], int K, int lane) {
+    if constexpr (G == kGroup) return group_sum_torch<E>(x, K, lane);
+    else return group_sum_torch_g<E, G>(x, K, lane);
+}
+
+template <int E, int W, int R, int G>
+__device__ __forceinline__ void mm_iterate_block(float (&beta)[R][E], const RowY<E, G> (&yv)[R], int K, int lane,
                                                  const bool (&active)[R], const LogTabEntry* tab, float* queue, QueueCtl* ctl,
                                                  int turn, bool measure, double (&num)[R], double (&den)[R]) {
+    constexpr int kGroups = (64 / G) * W;                        // lane groups (= rows per row set) of the block
     const int wave = threadIdx.x >> 6, lane64 = threadIdx.x & 63;
     float s[R];
     bool in_domain = true;
@@ -650,12 +657,12 @@ __device__ __forceinline__ void mm_iterate_block(float (&beta)[R][E], const RowY
     for (int r = 0; r < R; r++) {
         s[r] = 16.0f;
         if (active[r]) {
-            s[r] = group_sum_torch<E>(beta[r], K, lane);
+            s[r] = row_sum_torch<E, G>(beta[r], K, lane);
             in_domain = in_domain && fast_range_f32(s[r]) && s[r] <= 0x1p40f;
 #pragma unroll
             for (int e = 0; e < E; e++) in_domain = in_domain && mm_fast_domain(beta[r][e]);
         }
-        if (lane == 0) ctl->rowsum[turn & 1][r * (2 * W) + (threadIdx.x / kGroup)] = s[r];
+        if (lane == 0) ctl->rowsum[turn & 1][r * kGroups + (threadIdx.x / G)] = s[r];
         int idx = base[r];
 #pragma unroll
         for (int e = 0; e < E; e++) {
@@ -689,7 +696,7 @@ __device__ __forceinline__ void mm_iterate_block(float (&beta)[R][E], const RowY
 #pragma unroll
             for (int e = 0; e < E; e++) {
                 const float nb = mm_update_generic(beta[r][e], yv[r].get(e), psi_s);
-                const bool ok = e * kGroup + lane < K;
+                const bool ok = e * G + lane < K;
                 if (measure && ok) {
                     const double df = (double)nb - (double)beta[r][e];
                     num[r] += df * df;
@@ -713,16 +720,16 @@ __device__ __forceinline__ void mm_iterate_block(float (&beta)[R][E], const RowY
         const float r = lgamma_big_dense(v);
         if (j < n_big) queue[at] = r;
     }
-    // digamma of the 2 W R row sums: one lane per row, by the wave after the one that opens the dense pass
-    if (wave == (W - (turn % W) + 1) % W && lane64 < 2 * W * R)
+    // digamma of the block's row sums: one lane per row, by the wave after the one that opens the dense pass
+    if (wave == (W - (turn % W) + 1) % W && lane64 < kGroups * R)
         ctl->psi[turn & 1][lane64] = digamma_pos_f32(ctl->rowsum[turn & 1][lane64], tab);
     __syncthreads();
     // phase C: per element digamma, cheap lgamma branch, pick-up, algebra
 #pragma unroll
     for (int r = 0; r < R; r++)
         if (active[r])
-            mm_apply_updates<E>(beta[r], yv[r], K, lane, ctl->psi[turn & 1][r * (2 * W) + (threadIdx.x / kGroup)], tab, slice, base[r],
-                                measure, num[r], den[r]);
+            mm_apply_updates<E, G>(beta[r], yv[r], K, lane, ctl->psi[turn & 1][r * kGroups + (threadIdx.x / G)], tab, slice, base[r],
+                                   measure, num[r], den[r]);
 }
 
 #ifndef TCLIP_MM_BLOCK_WAVES
@@ -734,16 +741,19 @@ __device__ __forceinline__ void mm_iterate_block(float (&beta)[R][E], const RowY
 #endif
 // kDead: the listed rows are dead rows whose cache ends at this chunk: y = -10, the iterate lives in
 // `beta_dead` (their alpha keeps its value, em_dirichlet.py:224-226) and the stop-test pair goes to the cache.
-template <int E, int W, bool kDead, int R>
-__global__ __launch_bounds__(64 * W, (E > 8 ? TCLIP_MM_WAVES_LARGE : TCLIP_MM_WAVES_SMALL)) void k_mm_live(MMArgs a) {
+// G: lanes per row (32; 16 or 8 for short rows, where a 32-lane group would leave lanes idle: K = 100 fills
+// 100 of 128 slots as 32 x 4 but 100 of 104 as 8 x 13, with eight rows per wavefront sharing the per-row work).
+template <int E, int W, bool kDead, int R, int G = kGroup>
+__global__ __launch_bounds__(64 * W, (E * G > 256 ? TCLIP_MM_WAVES_LARGE : TCLIP_MM_WAVES_SMALL)) void k_mm_live(MMArgs a) {
     __shared__ LogTabEntry tab[16];
     __shared__ float queue[64 * W * E * R];
     __shared__ QueueCtl ctl;
     if (threadIdx.x == 0) ctl.bad = 0;
     load_log_table(tab);
-    const int lane = threadIdx.x & (kGroup - 1);
-    const int group = threadIdx.x / kGroup;
-    constexpr int kGroups = 2 * W, kRows = kGroups * R;
+    const int lane = threadIdx.x & (G - 1);
+    const int group = threadIdx.x / G;
+    constexpr int kGroups = (64 / G) * W, kRows = kGroups * R;
+    static_assert(kRows <= 64, "QueueCtl holds 64 row sums");
     int turn = 0;
     const int n = *a.n_rows;
     const int K = a.K;
@@ -767,32 +777,32 @@ __global__ __launch_bounds__(64 * W, (E > 8 ? TCLIP_MM_WAVES_LARGE : TCLIP_MM_WA
         const float* src = (kDead && a.chunk > 0) ? a.beta_dead : a.alpha;
         float* dst = kDead ? a.beta_dead : a.alpha;
         float beta[R][E];
-        RowY<E> yv[R];
+        RowY<E, G> yv[R];
         double num[R], den[R];
 #pragma unroll
         for (int r = 0; r < R; r++) {
             yv[r].load(kDead ? nullptr : a.y + (size_t)row[r] * K, lane, K);
 #pragma unroll
             for (int e = 0; e < E; e++) {
-                const int d = e * kGroup + lane;
+                const int d = e * G + lane;
                 beta[r][e] = (active[r] && d < K) ? src[(size_t)row[r] * K + d] : 0.0f;
             }
             num[r] = den[r] = 0.0;
         }
         for (int l = a.l0; l <= a.l1; l++)
-            mm_iterate_block<E, W, R>(beta, yv, K, lane, active, tab, queue, &ctl, turn++, a.has_check && l == a.l1, num, den);
+            mm_iterate_block<E, W, R, G>(beta, yv, K, lane, active, tab, queue, &ctl, turn++, a.has_check && l == a.l1, num, den);
 #pragma unroll
         for (int r = 0; r < R; r++) {
             if (!active[r]) continue;
 #pragma unroll
             for (int e = 0; e < E; e++) {
-                const int d = e * kGroup + lane;
+                const int d = e * G + lane;
                 if (d < K) dst[(size_t)row[r] * K + d] = beta[r][e];
             }
             if (a.work_counter && lane == 0)
                 atomicAdd(a.work_counter, (unsigned long long)K * (unsigned long long)(a.l1 - a.l0 + 1));
             if (a.has_check) {
-                const double sn = group_sum_f64(num[r]), sd = group_sum_f64(den[r]);
+                const double sn = group_sum_f64_g<G>(num[r]), sd = group_sum_f64_g<G>(den[r]);
                 if (lane == 0) {
                     double* out = kDead ? a.cache + ((size_t)row[r] * a.n_checks + a.chunk) * 2 : a.rowpart + 2 * (size_t)row[r];
                     out[0] = sn;
@@ -1703,32 +1713,60 @@ static void dispatch_E(int K, Args... args) {
 template <int E> struct LaunchMMProbe {
     static void run(int grid, hipStream_t st, MMArgs a) { hipLaunchKernelGGL(k_mm_probe<E>, dim3(grid), dim3(256), 0, st, a); }
 };
-template <int E> struct LaunchMMLive {
-    static constexpr int kWaves = E > 8 ? 4 : TCLIP_MM_BLOCK_WAVES;
-    static constexpr int kSets = E > 8 ? 1 : TCLIP_MM_ROWSETS;
-    static void run(int rows, hipStream_t st, MMArgs a) {
-        // two rows per lane group only when the row list can fill the machine with the larger blocks
-        // (256 CUs x 4 blocks); `rows` is the capacity of the list, the live count is known on the device only
-        const int min_rows = g_rowset_min_rows >= 0 ? g_rowset_min_rows : 2 * kWaves * kSets * 1024;
-        if (kSets > 1 && rows >= min_rows) {
-            int grid = (rows + 2 * kWaves * kSets - 1) / (2 * kWaves * kSets);
-            if (grid > 256 * 16) grid = 256 * 16;
-            hipLaunchKernelGGL((k_mm_live<E, kWaves, false, kSets>), dim3(grid), dim3(64 * kWaves), 0, st, a);
-            return;
-        }
-        int grid = (rows + 2 * kWaves - 1) / (2 * kWaves);
-        if (grid > 256 * 16) grid = 256 * 16;
-        hipLaunchKernelGGL((k_mm_live<E, kWaves, false, 1>), dim3(grid), dim3(64 * kWaves), 0, st, a);
+// The MM kernels: lanes per row and registers per lane from the row length.  Rows of up to 256 elements are spread
+// over 16 lanes (4 rows per wavefront, E = ceil(K / 16) registers), which fills the lanes (K = 100: 89 % as 16 x 7
+// instead of 78 % as 32 x 4; K = 10: 62 % instead of 31 %) and shares the per-row work among more rows.  Measured on
+// 1000 tasks (MM loop, 32 -> 16 lanes): K = 10 95 -> 71 ms, K = 37 186 -> 151, K = 47 217 -> 174, K = 100 476 -> 411
+// (460 with round 1's two rows per 32-lane group), K = 196 974 -> 895.  g_rowset_min_rows == 0 (test hook) forces the
+// 32-lane layout, which must give the same bits.
+#ifndef TCLIP_G8_MAX_K
+#define TCLIP_G8_MAX_K 0              // 8 lanes per row: measured slower than 16 at 1000 tasks (too few wavefronts: K = 10 / 37 / 47:
+                                      // 81 / 166 / 211 ms against 71 / 151 / 174), 2 % faster at 3000 tasks of K = 100; not compiled by default
+#endif
+#ifndef TCLIP_G16_MAX_K
+#define TCLIP_G16_MAX_K 256
+#endif
+#ifndef TCLIP_MM_LAUNCH_WAVES
+#define TCLIP_MM_LAUNCH_WAVES 4
+#endif
+template <int E, int G>
+static void launch_mm_EG(bool dead, int rows, hipStream_t st, const MMArgs& a) {
+    constexpr int kWaves = TCLIP_MM_LAUNCH_WAVES, kRowsPerBlock = (64 / G) * kWaves;
+    int grid = (rows + kRowsPerBlock - 1) / kRowsPerBlock;
+    if (grid > 256 * 16) grid = 256 * 16;
+    if (dead) hipLaunchKernelGGL((k_mm_live<E, kWaves, true, 1, G>), dim3(grid), dim3(64 * kWaves), 0, st, a);
+    else hipLaunchKernelGGL((k_mm_live<E, kWaves, false, 1, G>), dim3(grid), dim3(64 * kWaves), 0, st, a);
+}
+template <int G>
+static void launch_mm_G(int need, bool dead, int rows, hipStream_t st, const MMArgs& a) {
+    if (G < 32 || need <= 8) {
+        if (need <= 1) return launch_mm_EG<1, G>(dead, rows, st, a);
+        if (need <= 2) return launch_mm_EG<2, G>(dead, rows, st, a);
+        if (need <= 3) return launch_mm_EG<3, G>(dead, rows, st, a);
+        if (need <= 4) return launch_mm_EG<4, G>(dead, rows, st, a);
+        if (need <= 5) return launch_mm_EG<5, G>(dead, rows, st, a);
+        if (need <= 6) return launch_mm_EG<6, G>(dead, rows, st, a);
+        if (need <= 7) return launch_mm_EG<7, G>(dead, rows, st, a);
+        if (need <= 8) return launch_mm_EG<8, G>(dead, rows, st, a);
     }
-};
-template <int E> struct LaunchMMDead {
-    static constexpr int kWaves = LaunchMMLive<E>::kWaves;
-    static void run(int rows, hipStream_t st, MMArgs a) {
-        int grid = (rows + 2 * kWaves - 1) / (2 * kWaves);
-        if (grid > 256 * 16) grid = 256 * 16;
-        hipLaunchKernelGGL((k_mm_live<E, kWaves, true, 1>), dim3(grid), dim3(64 * kWaves), 0, st, a);
+    if (need <= 10) return launch_mm_EG<10, G>(dead, rows, st, a);
+    if (need <= 13) return launch_mm_EG<13, G>(dead, rows, st, a);
+    if (need <= 16) return launch_mm_EG<16, G>(dead, rows, st, a);
+    if constexpr (G == 32) {
+        if (need <= 20) return launch_mm_EG<20, G>(dead, rows, st, a);
+        if (need <= 24) return launch_mm_EG<24, G>(dead, rows, st, a);
+        if (need <= 28) return launch_mm_EG<28, G>(dead, rows, st, a);
+        return launch_mm_EG<32, G>(dead, rows, st, a);
     }
-};
+}
+static void launch_mm(bool dead, int K, int rows, hipStream_t st, const MMArgs& a) {
+    const bool wide = g_rowset_min_rows == 0;              // test hook: the 32-lane layout for every row length
+#if TCLIP_G8_MAX_K > 0
+    if (K <= TCLIP_G8_MAX_K && !wide) return launch_mm_G<8>((K + 7) / 8, dead, rows, st, a);
+#endif
+    if (K <= TCLIP_G16_MAX_K && !wide) launch_mm_G<16>((K + 15) / 16, dead, rows, st, a);
+    else launch_mm_G<32>((K + 31) / 32, dead, rows, st, a);
+}
 template <int E> struct LaunchRowConsts {
     static void run(int grid, hipStream_t st, const float* alpha, const int32_t* rows, const int32_t* n, int K, float* rowc) {
         hipLaunchKernelGGL(k_row_consts<E>, dim3(grid), dim3(256), 0, st, alpha, rows, n, K, rowc);
@@ -1896,7 +1934,7 @@ static int enqueue_batches(const tclip_problem& p, const float* x_q, const float
             hipEvent_t e0 = g_prof.on ? prof_event() : nullptr, e1 = g_prof.on ? prof_event() : nullptr;
             if (e0 && e1) TCLIP_HIP(hipEventRecord(e0, st));
             a.rows = live_rows; a.n_rows = counts + 1;
-            dispatch_E<LaunchMMLive>(K, TK, st, a);
+            launch_mm(false, K, TK, st, a);
             if (e0 && e1) TCLIP_HIP(hipEventRecord(e1, st));    // the instrumentation covers k_mm_live only
             if (zs && a.has_check) {          // dead rows only matter through their stop-test terms
                 a.rows = dead_list[c & 1]; a.n_rows = dead_counts + c; a.work_counter = nullptr;
@@ -1906,7 +1944,7 @@ static int enqueue_batches(const tclip_problem& p, const float* x_q, const float
                 int32_t* next_rows = more ? dead_list[(c + 1) & 1] : nullptr;
                 int32_t* next_count = more ? dead_counts + c + 1 : nullptr;
                 a.next_rows = probe ? nullptr : next_rows; a.next_count = probe ? nullptr : next_count;
-                dispatch_E<LaunchMMDead>(K, TK, st, a);
+                launch_mm(true, K, TK, st, a);
                 a.next_rows = next_rows; a.next_count = next_count;
                 if (probe) dispatch_E<LaunchMMProbe>(K, grid, st, a);
             }

@@ -22,6 +22,7 @@ _SIGNATURES = {
     "tclip_prototype_workspace_bytes": (ctypes.c_size_t, [ctypes.c_int32] * 3),
     "tclip_cluster_prototypes": (ctypes.c_int, [ctypes.c_int32] * 3 + [_P] * 6 + [ctypes.c_size_t, _P]),
     "tclip_match_clusters_host": (ctypes.c_int, [ctypes.c_int32] * 3 + [_P] * 5 + [ctypes.c_int32, _P, _P]),
+    "tclip_match_clusters_host_strided": (ctypes.c_int, [ctypes.c_int32] * 3 + [_P] * 5 + [ctypes.c_int32, ctypes.c_int32, _P, _P]),
     "tclip_gather_rows": (ctypes.c_int, [_P, ctypes.c_int64, ctypes.c_int32, _P, ctypes.c_int64, _P, _P]),
     "tclip_soft_kmeans_workspace_bytes": (ctypes.c_size_t, [ctypes.POINTER(Problem)]),
     "tclip_soft_kmeans_run": (ctypes.c_int, [ctypes.POINTER(Problem), _P, ctypes.c_float, _P, _P, _P, _P, ctypes.c_size_t, _P]),

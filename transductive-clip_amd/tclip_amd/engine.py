@@ -207,18 +207,20 @@ def clustering_accuracy(x_q, preds, y_q, graph_matching=True):
         off = (-ws.data_ptr()) % 256
         n_clusters = torch.empty(T, dtype=torch.int32, device=dev)
         ids = torch.empty(T, cmax, dtype=torch.int32, device=dev)
-        protos = torch.zeros(T, cmax, K, device=dev)
+        protos = torch.empty(T, cmax, K, device=dev)        # rows beyond a task's cluster count are never read
         preds = preds.to(dev).int().contiguous()
         rc = lib.tclip_cluster_prototypes(T, Q, K, _ptr(x_q), _ptr(preds), _ptr(n_clusters), _ptr(ids), _ptr(protos),
                                           ctypes.c_void_p(ws.data_ptr() + off), ws_bytes, _stream())
         _capi.check(rc, "tclip_cluster_prototypes")
-        preds_h, nc_h, ids_h, protos_h = preds.cpu(), n_clusters.cpu(), ids.cpu(), protos.cpu()
+        preds_h, nc_h = preds.cpu(), n_clusters.cpu()
+        used = max(1, min(cmax, int(nc_h.max())))          # rows of the fullest task: only those travel to the host
+        ids_h, protos_h = ids[:, :used].contiguous().cpu(), protos[:, :used].contiguous().cpu()
     y_h = y_q.reshape(T, Q).long().cpu().contiguous()
     new_preds = torch.empty(T, Q, dtype=torch.int32)
     acc = torch.empty(T, dtype=torch.float32)
-    rc = lib.tclip_match_clusters_host(T, Q, K, _ptr(preds_h), _ptr(nc_h), _ptr(ids_h), _ptr(protos_h), _ptr(y_h),
-                                       int(bool(graph_matching)), _ptr(new_preds), _ptr(acc))
-    _capi.check(rc, "tclip_match_clusters_host")
+    rc = lib.tclip_match_clusters_host_strided(T, Q, K, _ptr(preds_h), _ptr(nc_h), _ptr(ids_h), _ptr(protos_h), _ptr(y_h),
+                                               int(bool(graph_matching)), used, _ptr(new_preds), _ptr(acc))
+    _capi.check(rc, "tclip_match_clusters_host_strided")
     return acc, new_preds
 
 
@@ -241,8 +243,8 @@ def debug_set_probe_chunks(chunks=-1):
 
 
 def debug_set_rowset_min_rows(rows=-1):
-    """Test hook: row-list size from which live rows advance two per lane group (0 = always,
-    2**30 = never, negative = default rule).  Results do not depend on it."""
+    """Test hook: 0 forces the 32-lanes-per-row layout of the MM kernels for every row length (short rows
+    normally use 8 or 16 lanes per row), negative restores the default rule.  Results do not depend on it."""
     _capi.check(_capi.lib().tclip_debug_set_rowset_min_rows(int(rows)), "tclip_debug_set_rowset_min_rows")
 
 
