@@ -91,10 +91,12 @@ def test_limit_cycle_shortcut_is_exact(K, N, B):
 
 @pytest.mark.parametrize("K,N,B,hard", [(2, 5, 2, False), (7, 6, 2, False), (10, 7, 3, False), (37, 5, 2, True), (47, 4, 2, False),
                                         (64, 3, 2, False), (65, 3, 2, True), (100, 6, 2, False), (102, 4, 1, False), (128, 3, 1, False),
-                                        (129, 3, 1, False), (196, 3, 1, False), (200, 3, 1, False), (256, 2, 1, False), (33, 4, 2, False)])
+                                        (129, 3, 1, False), (196, 3, 1, False), (200, 3, 1, False), (256, 2, 1, False), (33, 4, 2, False),
+                                        (897, 2, 1, False), (1000, 2, 2, True), (1001, 2, 1, False), (1024, 2, 1, False)])
 def test_lane_layouts_are_equivalent(K, N, B, hard):
-    """Short rows are spread over 8 or 16 lanes instead of 32 (several rows per wavefront, fuller lanes); the
-    row sum keeps torch's association order in every layout.  The default layout and the forced 32-lane layout
+    """Rows of up to 256 elements are spread over 16 lanes instead of 32 (several rows per wavefront, fuller lanes),
+    rows of 897+ over a whole wavefront (two halves that build the two terms of torch's 16-step cascade); the row
+    sum keeps torch's association order in every layout.  The default layout and the forced 32-lane layout
     must give the same bits on the same problem (ragged row counts, several batches, a few-shot case)."""
     from tclip_amd import engine, synth
     x_q, _ = synth.make_query_tasks(B * N, K, seed=70 + K)

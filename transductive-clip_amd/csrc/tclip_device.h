@@ -136,6 +136,41 @@ __device__ __forceinline__ float group_sum_torch_g(const float (&x)[E], int K, i
     return fin;
 }
 
+// A row of 512 < K <= 1024 elements on a whole wavefront: lane 32 q + l (q = 0, 1) holds elements
+// 512 q + 32 e + l in register e (E = 16).  torch's 4-way interleaved accumulators dump their running sums
+// every 16 steps, so accumulator (l / 8, l % 8) is RN(sum of steps 0..15) + RN(sum of steps 16..) - the two
+// halves of the wavefront build the two terms independently.  Valid in all 64 lanes.
+template <int E>
+__device__ __forceinline__ float group_sum_torch_64(const float (&x)[E], int K, int lane) {
+    static_assert(E == 16, "two halves of 16 steps");
+    const int vec_size = K >> 3, size_ilp = vec_size >> 2;       // 16 <= size_ilp <= 32
+    const int q = lane >> 5, l = lane & 31, j = l & 7;
+    float acc = 0.0f, ragged = 0.0f;
+#pragma unroll
+    for (int e = 0; e < E; e++) {
+        const int m = e + 16 * q;
+        if (m < size_ilp) acc += x[e];
+        if (m == size_ilp) ragged = x[e];
+    }
+    const float pm = acc + __shfl_xor(acc, 32, 64);               // a0 + a1 (either order: one addition)
+    const int rq = (size_ilp >> 4) * 32;                           // the half that holds the ragged step
+    const int nleft = vec_size - 4 * size_ilp;
+    float p0 = pm;
+    const float l0 = __shfl(ragged, rq + j, 64), l1 = __shfl(ragged, rq + 8 + j, 64), l2 = __shfl(ragged, rq + 16 + j, 64);
+    if (nleft >= 1) p0 += l0;
+    if (nleft >= 2) p0 += l1;
+    if (nleft >= 3) p0 += l2;
+    p0 += __shfl(pm, 8 + j, 64);
+    p0 += __shfl(pm, 16 + j, 64);
+    p0 += __shfl(pm, 24 + j, 64);                                 // valid in lanes 0..7
+    const int ntail = K - 8 * vec_size, tail_base = rq + 8 * (vec_size & 3);
+    float fin = 0.0f;
+    for (int t = 0; t < ntail; t++) fin += __shfl(ragged, tail_base + t, 64);
+#pragma unroll
+    for (int t = 0; t < 8; t++) fin += __shfl(p0, t, 64);
+    return fin;
+}
+
 template <int G>
 __device__ __forceinline__ double group_sum_f64_g(double v) {
 #pragma unroll

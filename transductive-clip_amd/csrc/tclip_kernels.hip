@@ -384,6 +384,21 @@ struct MMArgs {
 #ifndef TCLIP_Y_REGS_MAX_E
 #define TCLIP_Y_REGS_MAX_E 16
 #endif
+// Element held by register e of lane `lane` of a row's lane group.  G <= 32: element e G + lane.  G = 64 (rows of
+// 897..1024 elements, one wavefront per row): lanes 0..31 hold the first 16 steps of 32 elements, lanes 32..63 the
+// rest, so that each half accumulates its part of torch's 16-step cascade locally (see group_sum_torch_64).
+template <int E, int G>
+__device__ __forceinline__ int elem_of(int e, int lane) {
+    if constexpr (G == 64) return (lane >> 5) * (E * 32) + e * 32 + (lane & 31);
+    else return e * G + lane;
+}
+// registers below this index hold only elements inside the row (wave-uniform)
+template <int E, int G>
+__device__ __forceinline__ int full_registers(int K) {
+    if constexpr (G == 64) return K > E * 32 ? (K - E * 32) / 32 : 0;
+    else return K / G;
+}
+
 template <int E, int G = kGroup>
 struct RowY {
     static constexpr bool kInRegs = E <= TCLIP_Y_REGS_MAX_E;
@@ -391,11 +406,11 @@ struct RowY {
     const float* g;      // row base in global memory, or nullptr for a dead row (y = -10)
     int lane, K, n_full; // n_full = K / 32: registers below it lie entirely inside the row (wave-uniform)
     __device__ __forceinline__ void load(const float* row_y, int lane_, int K_) {
-        g = row_y; lane = lane_; K = K_; n_full = K_ / G;
+        g = row_y; lane = lane_; K = K_; n_full = full_registers<E, G>(K_);
         if (kInRegs) {
 #pragma unroll
             for (int e = 0; e < (kInRegs ? E : 1); e++) {
-                const int d = e * G + lane;
+                const int d = elem_of<E, G>(e, lane);
                 r[e] = d < K ? (g ? g[d] : -10.0f) : 0.0f;
             }
         }
@@ -403,7 +418,7 @@ struct RowY {
     __device__ __forceinline__ float get(int e) const {
         if (kInRegs) return r[kInRegs ? e : 0];
         if (!g) return -10.0f;                       // dead rows: y is not read by lanes beyond the row either
-        const int d = e * G + lane;
+        const int d = elem_of<E, G>(e, lane);
         if (e < n_full) return g[d];                 // uniform branch: no lane mask on the load
         return d < K ? g[d] : 0.0f;
     }
@@ -435,7 +450,7 @@ template <int E, int G = kGroup>
 __device__ __forceinline__ void mm_apply_updates(float (&beta)[E], const RowY<E, G>& yv, int K, int lane, float psi_s,
                                                  const LogTabEntry* tab, const float* queue, int base, bool measure,
                                                  double& num, double& den) {
-    const int n_full = K / G;                      // registers below it hold G elements of the row (wave-uniform)
+    const int n_full = full_registers<E, G>(K);    // registers below it hold only elements of the row (wave-uniform)
 #pragma unroll
     for (int p = 0; p < (TCLIP_MM_PACKED ? E / 2 : 0); p++) {
         const int e = 2 * p;
@@ -449,7 +464,7 @@ __device__ __forceinline__ void mm_apply_updates(float (&beta)[E], const RowY<E,
         base += __popcll(m1);
         const f2 nb = pk_mm_update(a, f2{yv.get(e), yv.get(e + 1)}, pk(psi_s), f2{lg0, lg1}, tab);
         const bool full = e + 1 < n_full;
-        const bool ok0 = full || e * G + lane < K, ok1 = full || (e + 1) * G + lane < K;
+        const bool ok0 = full || elem_of<E, G>(e, lane) < K, ok1 = full || elem_of<E, G>(e + 1, lane) < K;
         if (measure) {
             const double d0 = (double)nb.x - (double)a.x, d1 = (double)nb.y - (double)a.y;
             if (ok0) { num += d0 * d0; den += (double)a.x * (double)a.x; }
@@ -476,7 +491,7 @@ __device__ __forceinline__ void mm_apply_updates(float (&beta)[E], const RowY<E,
         if (__builtin_expect(__builtin_amdgcn_ballot_w64(!sure) != 0ull, 0)) lg_small = sure ? lg_small : lgamma_sleef_05_23(big ? 2.0f : x1);
         const float psi1 = digamma_xp1(a, tab);
         const float nb = mm_update_algebra(a, yv.get(e), psi_s, psi1, big ? lg_big : lg_small);
-        const bool ok = e * G + lane < K;
+        const bool ok = elem_of<E, G>(e, lane) < K;
         if (measure && ok) {
             const double df = (double)nb - (double)a;
             num += df * df;
@@ -638,6 +653,7 @@ struct QueueCtl { int count[2][8]; int bad; float rowsum[2][64]; float psi[2][64
 template <int E, int G>
 __device__ __forceinline__ float row_sum_torch(const float (&x)[E], int K, int lane) {
     if constexpr (G == kGroup) return group_sum_torch<E>(x, K, lane);
+    else if constexpr (G == 64) return group_sum_torch_64<E>(x, K, lane);
     else return group_sum_torch_g<E, G>(x, K, lane);
 }
 
@@ -696,7 +712,7 @@ __device__ __forceinline__ void mm_iterate_block(float (&beta)[R][E], const RowY
 #pragma unroll
             for (int e = 0; e < E; e++) {
                 const float nb = mm_update_generic(beta[r][e], yv[r].get(e), psi_s);
-                const bool ok = e * G + lane < K;
+                const bool ok = elem_of<E, G>(e, lane) < K;
                 if (measure && ok) {
                     const double df = (double)nb - (double)beta[r][e];
                     num[r] += df * df;
@@ -744,7 +760,7 @@ __device__ __forceinline__ void mm_iterate_block(float (&beta)[R][E], const RowY
 // G: lanes per row (32; 16 or 8 for short rows, where a 32-lane group would leave lanes idle: K = 100 fills
 // 100 of 128 slots as 32 x 4 but 100 of 104 as 8 x 13, with eight rows per wavefront sharing the per-row work).
 template <int E, int W, bool kDead, int R, int G = kGroup>
-__global__ __launch_bounds__(64 * W, (E * G > 256 ? TCLIP_MM_WAVES_LARGE : TCLIP_MM_WAVES_SMALL)) void k_mm_live(MMArgs a) {
+__global__ __launch_bounds__(64 * W, (E * G > 256 && G < 64 ? TCLIP_MM_WAVES_LARGE : TCLIP_MM_WAVES_SMALL)) void k_mm_live(MMArgs a) {
     __shared__ LogTabEntry tab[16];
     __shared__ float queue[64 * W * E * R];
     __shared__ QueueCtl ctl;
@@ -784,7 +800,7 @@ __global__ __launch_bounds__(64 * W, (E * G > 256 ? TCLIP_MM_WAVES_LARGE : TCLIP
             yv[r].load(kDead ? nullptr : a.y + (size_t)row[r] * K, lane, K);
 #pragma unroll
             for (int e = 0; e < E; e++) {
-                const int d = e * G + lane;
+                const int d = elem_of<E, G>(e, lane);
                 beta[r][e] = (active[r] && d < K) ? src[(size_t)row[r] * K + d] : 0.0f;
             }
             num[r] = den[r] = 0.0;
@@ -796,7 +812,7 @@ __global__ __launch_bounds__(64 * W, (E * G > 256 ? TCLIP_MM_WAVES_LARGE : TCLIP
             if (!active[r]) continue;
 #pragma unroll
             for (int e = 0; e < E; e++) {
-                const int d = e * G + lane;
+                const int d = elem_of<E, G>(e, lane);
                 if (d < K) dst[(size_t)row[r] * K + d] = beta[r][e];
             }
             if (a.work_counter && lane == 0)
@@ -1726,6 +1742,10 @@ template <int E> struct LaunchMMProbe {
 #ifndef TCLIP_G16_MAX_K
 #define TCLIP_G16_MAX_K 256
 #endif
+#ifndef TCLIP_G64_MIN_K
+#define TCLIP_G64_MIN_K 897           // rows from this length on: one wavefront per row, 16 registers per lane instead of 32 lanes x 32
+                                      // registers (half the code, 4 instead of 3 wavefronts per SIMD): K = 1000 bench shape 12.55 -> 11.90 s
+#endif
 #ifndef TCLIP_MM_LAUNCH_WAVES
 #define TCLIP_MM_LAUNCH_WAVES 4
 #endif
@@ -1761,6 +1781,9 @@ static void launch_mm_G(int need, bool dead, int rows, hipStream_t st, const MMA
 }
 static void launch_mm(bool dead, int K, int rows, hipStream_t st, const MMArgs& a) {
     const bool wide = g_rowset_min_rows == 0;              // test hook: the 32-lane layout for every row length
+#if TCLIP_G64_MIN_K > 0
+    if (K >= TCLIP_G64_MIN_K && K >= 512 && !wide) return launch_mm_EG<16, 64>(dead, rows, st, a);   // 512: the cascade's first dump
+#endif
 #if TCLIP_G8_MAX_K > 0
     if (K <= TCLIP_G8_MAX_K && !wide) return launch_mm_G<8>((K + 7) / 8, dead, rows, st, a);
 #endif
