@@ -760,7 +760,9 @@ __device__ __forceinline__ void mm_iterate_block(float (&beta)[R][E], const RowY
 // G: lanes per row (32; 16 or 8 for short rows, where a 32-lane group would leave lanes idle: K = 100 fills
 // 100 of 128 slots as 32 x 4 but 100 of 104 as 8 x 13, with eight rows per wavefront sharing the per-row work).
 template <int E, int W, bool kDead, int R, int G = kGroup>
-__global__ __launch_bounds__(64 * W, (E * G > 256 && G < 64 ? TCLIP_MM_WAVES_LARGE : TCLIP_MM_WAVES_SMALL)) void k_mm_live(MMArgs a) {
+// wavefronts per SIMD: 4 (128 VGPRs) up to 16 registers per lane - also for K = 257..512 as 32 lanes x 10..16 since round 2
+// (K = 397, hard, 1000 tasks: 1.24 -> 1.18 s) - 3 (168 VGPRs) for the 20..28-register kernels
+__global__ __launch_bounds__(64 * W, (E > 16 ? TCLIP_MM_WAVES_LARGE : TCLIP_MM_WAVES_SMALL)) void k_mm_live(MMArgs a) {
     __shared__ LogTabEntry tab[16];
     __shared__ float queue[64 * W * E * R];
     __shared__ QueueCtl ctl;
