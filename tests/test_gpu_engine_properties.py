@@ -120,7 +120,7 @@ def test_lane_layouts_are_equivalent(K, N, B, hard):
         assert torch.equal(r.alpha, runs[0].alpha) and torch.equal(r.u, runs[0].u) and torch.equal(r.v, runs[0].v)
 
 
-@pytest.mark.parametrize("K,N", [(12, 3), (40, 4)])
+@pytest.mark.parametrize("K,N", [(12, 3), (40, 4), (300, 2), (900, 2)])      # 16, 16, 32 and 64 lanes per row
 def test_nan_in_one_task_leaves_the_others_exact(K, N):
     """A NaN feature poisons its own task (as in the reference) and pushes every block that holds
     one of that task's rows onto the generic IEEE path of the MM kernel, iteration after iteration;

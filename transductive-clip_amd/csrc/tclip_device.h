@@ -25,12 +25,35 @@ namespace tclip {
 constexpr int kGroup = 32;          // lanes per row
 constexpr float kEpsF = 1e-15f;
 
+// v from the lane N places up inside the 16-lane DPP row (row_shl:N); lanes whose source falls outside the row get 0.
+// One VALU operand modifier instead of a ds_bpermute through the LDS crossbar.
+template <int N>
+__device__ __forceinline__ float dpp_row_shl(float v) {
+    static_assert(N >= 1 && N <= 15, "row_shl");
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x100 + N, 0xf, 0xf, true));
+}
+// fin + p0[0] + p0[1] + ... + p0[7] in that order, p0[t] being lane t's value; the result is valid in lane 0 of every
+// 16-lane row (callers: the first lane of a row's lane group, which starts a DPP row in every layout).
+__device__ __forceinline__ float ordered_sum8_lane0(float fin, float p0) {
+    fin += p0;
+    fin += dpp_row_shl<1>(p0);
+    fin += dpp_row_shl<2>(p0);
+    fin += dpp_row_shl<3>(p0);
+    fin += dpp_row_shl<4>(p0);
+    fin += dpp_row_shl<5>(p0);
+    fin += dpp_row_shl<6>(p0);
+    fin += dpp_row_shl<7>(p0);
+    return fin;
+}
+
 __device__ __forceinline__ float group_shfl(float v, int src_lane) { return __shfl(v, src_lane, kGroup); }
 __device__ __forceinline__ double group_shfl_xor(double v, int m) { return __shfl_xor(v, m, kGroup); }
 
 // x[e] holds element 32e + lane (0 where 32e + lane >= K).  Returns torch's x.sum(-1), the same
 // value in all 32 lanes of the group.
-template <int E>
+// kLane0: the caller needs the sum in lane 0 of the group only (the last eight additions then take their operands
+// through DPP instead of eight LDS-crossbar shuffles).
+template <int E, bool kLane0 = false>
 __device__ __forceinline__ float group_sum_torch(const float (&x)[E], int K, int lane) {
     if (K < 8) {  // scalar_inner_sum: 4 interleaved scalar accumulators
         const int size_ilp = K >> 2;
@@ -68,6 +91,7 @@ __device__ __forceinline__ float group_sum_torch(const float (&x)[E], int K, int
     const int ntail = K - 8 * vec_size, tail_base = 8 * (vec_size & 3);
     float fin = 0.0f;
     for (int t = 0; t < ntail; t++) fin += group_shfl(ragged, tail_base + t);    // wave-uniform trip count (0..7)
+    if (kLane0) return ordered_sum8_lane0(fin, p0);
 #pragma unroll
     for (int t = 0; t < 8; t++) fin += group_shfl(p0, t);
     return fin;
@@ -77,7 +101,7 @@ __device__ __forceinline__ float group_sum_torch(const float (&x)[E], int K, int
 // Element d lives in register d / G of lane d % G.  With H = G / 8 lanes-of-eight per group, lane (h, j) =
 // 8 h + j holds the 8-float vector v = e H + h in register e; torch's accumulator r = v % 4 and step m = v / 4
 // are r = (e % P) H + h, m = e / P with P = 4 / H registers per step, so a lane keeps P partial sums.
-template <int E, int G>
+template <int E, int G, bool kLane0 = false>
 __device__ __forceinline__ float group_sum_torch_g(const float (&x)[E], int K, int lane) {
     static_assert(G == 8 || G == 16, "lanes per row");
     constexpr int H = G / 8, P = 4 / H;
@@ -122,7 +146,11 @@ __device__ __forceinline__ float group_sum_torch_g(const float (&x)[E], int K, i
         if (i < nleft) p0 += v;
     }
 #pragma unroll
-    for (int r = 1; r < 4; r++) p0 += shfl(pm[r / H], 8 * (r % H) + j);      // valid in lanes 0..7
+    for (int r = 1; r < 4; r++) {                                            // valid in lanes 0..7
+        if (r % H == 0) p0 += pm[r / H];                                     // own lane's other accumulator
+        else if (kLane0 && G == 16) p0 += dpp_row_shl<8>(pm[r / H]);         // lane 8 + j of the same DPP row
+        else p0 += shfl(pm[r / H], 8 * (r % H) + j);
+    }
     // scalar tail (K mod 8 elements, in the partial vector vec_size) first, then the 8 vector lanes in order
     const int ntail = K - 8 * vec_size, tv = vec_size & 3;   // the partial vector is vector tv of the ragged step
     float fin = 0.0f;
@@ -131,6 +159,7 @@ __device__ __forceinline__ float group_sum_torch_g(const float (&x)[E], int K, i
         if (i == tv)                                         // wave-uniform
             for (int t = 0; t < ntail; t++) fin += shfl(rag[i / H], 8 * (i % H) + t);
     }
+    if (kLane0) return ordered_sum8_lane0(fin, p0);
 #pragma unroll
     for (int t = 0; t < 8; t++) fin += shfl(p0, t);
     return fin;
@@ -140,7 +169,7 @@ __device__ __forceinline__ float group_sum_torch_g(const float (&x)[E], int K, i
 // 512 q + 32 e + l in register e (E = 16).  torch's 4-way interleaved accumulators dump their running sums
 // every 16 steps, so accumulator (l / 8, l % 8) is RN(sum of steps 0..15) + RN(sum of steps 16..) - the two
 // halves of the wavefront build the two terms independently.  Valid in all 64 lanes.
-template <int E>
+template <int E, bool kLane0 = false>
 __device__ __forceinline__ float group_sum_torch_64(const float (&x)[E], int K, int lane) {
     static_assert(E == 16, "two halves of 16 steps");
     const int vec_size = K >> 3, size_ilp = vec_size >> 2;       // 16 <= size_ilp <= 32
@@ -166,6 +195,7 @@ __device__ __forceinline__ float group_sum_torch_64(const float (&x)[E], int K, 
     const int ntail = K - 8 * vec_size, tail_base = rq + 8 * (vec_size & 3);
     float fin = 0.0f;
     for (int t = 0; t < ntail; t++) fin += __shfl(ragged, tail_base + t, 64);
+    if (kLane0) return ordered_sum8_lane0(fin, p0);
 #pragma unroll
     for (int t = 0; t < 8; t++) fin += __shfl(p0, t, 64);
     return fin;

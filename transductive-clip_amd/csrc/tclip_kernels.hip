@@ -501,11 +501,19 @@ __device__ __forceinline__ void mm_apply_updates(float (&beta)[E], const RowY<E,
     }
 }
 
-template <int E>
-__device__ __forceinline__ void mm_iterate(float (&beta)[E], const RowY<E>& yv, int K, int lane,
+// the row sum in torch's order, valid in every lane of the row's lane group
+template <int E, int G>
+__device__ __forceinline__ float row_sum_torch_all(const float (&x)[E], int K, int lane) {
+    if constexpr (G == kGroup) return group_sum_torch<E>(x, K, lane);
+    else if constexpr (G == 64) return group_sum_torch_64<E>(x, K, lane);
+    else return group_sum_torch_g<E, G>(x, K, lane);
+}
+
+template <int E, int G>
+__device__ __forceinline__ void mm_iterate(float (&beta)[E], const RowY<E, G>& yv, int K, int lane,
                                            const LogTabEntry* tab, float* queue, bool measure, double& num,
                                            double& den) {
-    const float s = group_sum_torch<E>(beta, K, lane);
+    const float s = row_sum_torch_all<E, G>(beta, K, lane);
     bool in_domain = fast_range_f32(s) && s <= 0x1p40f;
 #pragma unroll
     for (int e = 0; e < E; e++) in_domain = in_domain && mm_fast_domain(beta[e]);
@@ -514,7 +522,7 @@ __device__ __forceinline__ void mm_iterate(float (&beta)[E], const RowY<E>& yv, 
 #pragma unroll
         for (int e = 0; e < E; e++) {
             const float nb = mm_update_generic(beta[e], yv.get(e), psi_s);
-            const bool ok = e * kGroup + lane < K;
+            const bool ok = elem_of<E, G>(e, lane) < K;
             if (measure && ok) {
                 const double df = (double)nb - (double)beta[e];
                 num += df * df;
@@ -548,7 +556,7 @@ __device__ __forceinline__ void mm_iterate(float (&beta)[E], const RowY<E>& yv, 
     }
     __builtin_amdgcn_wave_barrier();
     // phase C: per element digamma, cheap lgamma branch, pick-up, algebra
-    mm_apply_updates<E>(beta, yv, K, lane, psi_s, tab, queue, 0, measure, num, den);
+    mm_apply_updates<E, G>(beta, yv, K, lane, psi_s, tab, queue, 0, measure, num, den);
     __builtin_amdgcn_wave_barrier();
 }
 
@@ -573,16 +581,16 @@ constexpr int kMaxCycle = TCLIP_MAX_CYCLE;  // longest limit cycle looked for on
 // for ever, so every later checkpoint's (||b'-b||^2, ||b||^2) is one of the p pairs measured
 // here: the remaining ~900 iterations of this row need not be executed.  No cycle within
 // kMaxCycle steps: nothing is assumed, the row keeps iterating chunk by chunk.
-template <int E>
-__global__ __launch_bounds__(256, (E > 8 ? TCLIP_MM_WAVES_LARGE : TCLIP_MM_WAVES_SMALL)) void k_mm_probe(MMArgs a) {
+template <int E, int G>
+__global__ __launch_bounds__(256, (E > 16 ? TCLIP_MM_WAVES_LARGE : TCLIP_MM_WAVES_SMALL)) void k_mm_probe(MMArgs a) {
     __shared__ LogTabEntry tab[16];
-    __shared__ double cyc[8][kMaxCycle][2];
+    __shared__ double cyc[256 / G][kMaxCycle][2];
     __shared__ float lg_queue[4][64 * E];             // per wave: arguments / results of the large-x lgamma
     load_log_table(tab);
     float* queue = lg_queue[threadIdx.x >> 6];
-    const int lane = threadIdx.x & (kGroup - 1);
-    const int group = threadIdx.x / kGroup;
-    const int groups_per_block = blockDim.x / kGroup;
+    const int lane = threadIdx.x & (G - 1);
+    const int group = threadIdx.x / G;
+    const int groups_per_block = blockDim.x / G;
     const int n = *a.n_rows;
     const int K = a.K;
     for (int i = blockIdx.x * groups_per_block + group; i < n; i += gridDim.x * groups_per_block) {
@@ -595,29 +603,30 @@ __global__ __launch_bounds__(256, (E > 8 ? TCLIP_MM_WAVES_LARGE : TCLIP_MM_WAVES
         }
         const float* ref = a.beta_dead + (size_t)row * K;          // b_{l1+1}
         float beta[E];
-        RowY<E> yv;
+        RowY<E, G> yv;
         yv.load(nullptr, lane, K);
 #pragma unroll
         for (int e = 0; e < E; e++) {
-            const int d = e * kGroup + lane;
+            const int d = elem_of<E, G>(e, lane);
             beta[e] = d < K ? ref[d] : 0.0f;
         }
         int period = 0;
         for (int j = 0; j < kMaxCycle && period == 0; j++) {
             double pn = 0.0, pd = 0.0;
-            mm_iterate<E>(beta, yv, K, lane, tab, queue, true, pn, pd);
-            pn = group_sum_f64(pn);
-            pd = group_sum_f64(pd);
+            mm_iterate<E, G>(beta, yv, K, lane, tab, queue, true, pn, pd);
+            pn = group_sum_f64_g<G>(pn);
+            pd = group_sum_f64_g<G>(pd);
             if (lane == 0) { cyc[group][j][0] = pn; cyc[group][j][1] = pd; }
             bool same = true;
 #pragma unroll
             for (int e = 0; e < E; e++) {
-                const int d = e * kGroup + lane;
+                const int d = elem_of<E, G>(e, lane);
                 if (d < K) same = same && (beta[e] == ref[d]);
             }
             const unsigned long long bal = __ballot(same);
-            const unsigned int mine = (unsigned int)(bal >> ((threadIdx.x & 32) ? 32 : 0));
-            if (mine == 0xffffffffu) period = j + 1;
+            constexpr unsigned long long kAll = G == 64 ? ~0ull : (1ull << (G & 63)) - 1ull;
+            const unsigned long long mine = (bal >> ((threadIdx.x & 63) & ~(G - 1))) & kAll;      // this group's lanes
+            if (mine == kAll) period = j + 1;
         }
         if (period && lane == 0) {
             for (int m = a.chunk + 1; m < a.n_checks; m++) {         // the checkpoints still ahead
@@ -650,11 +659,12 @@ __global__ __launch_bounds__(256, (E > 8 ? TCLIP_MM_WAVES_LARGE : TCLIP_MM_WAVES
 // dense-pass window instead of every 32-lane group evaluating its own row's value 32 times over.
 struct QueueCtl { int count[2][8]; int bad; float rowsum[2][64]; float psi[2][64]; };
 
+// the row sum in torch's order, valid in lane 0 of the row's lane group (K >= 8; shorter rows: in every lane)
 template <int E, int G>
 __device__ __forceinline__ float row_sum_torch(const float (&x)[E], int K, int lane) {
-    if constexpr (G == kGroup) return group_sum_torch<E>(x, K, lane);
-    else if constexpr (G == 64) return group_sum_torch_64<E>(x, K, lane);
-    else return group_sum_torch_g<E, G>(x, K, lane);
+    if constexpr (G == kGroup) return group_sum_torch<E, true>(x, K, lane);
+    else if constexpr (G == 64) return group_sum_torch_64<E, true>(x, K, lane);
+    else return group_sum_torch_g<E, G, true>(x, K, lane);
 }
 
 template <int E, int W, int R, int G>
@@ -674,7 +684,7 @@ __device__ __forceinline__ void mm_iterate_block(float (&beta)[R][E], const RowY
         s[r] = 16.0f;
         if (active[r]) {
             s[r] = row_sum_torch<E, G>(beta[r], K, lane);
-            in_domain = in_domain && fast_range_f32(s[r]) && s[r] <= 0x1p40f;
+            in_domain = in_domain && (lane != 0 || (fast_range_f32(s[r]) && s[r] <= 0x1p40f));     // the sum lives in lane 0
 #pragma unroll
             for (int e = 0; e < E; e++) in_domain = in_domain && mm_fast_domain(beta[r][e]);
         }
@@ -708,7 +718,7 @@ __device__ __forceinline__ void mm_iterate_block(float (&beta)[R][E], const RowY
 #pragma unroll
         for (int r = 0; r < R; r++) {
             if (!active[r]) continue;
-            const float psi_s = digamma_f32(s[r]);
+            const float psi_s = digamma_f32(ctl->rowsum[turn & 1][r * kGroups + (threadIdx.x / G)]);   // lane 0's row sum
 #pragma unroll
             for (int e = 0; e < E; e++) {
                 const float nb = mm_update_generic(beta[r][e], yv[r].get(e), psi_s);
@@ -1728,9 +1738,6 @@ static void dispatch_E(int K, Args... args) {
     else Launcher<32>::run(args...);
 }
 
-template <int E> struct LaunchMMProbe {
-    static void run(int grid, hipStream_t st, MMArgs a) { hipLaunchKernelGGL(k_mm_probe<E>, dim3(grid), dim3(256), 0, st, a); }
-};
 // The MM kernels: lanes per row and registers per lane from the row length.  Rows of up to 256 elements are spread
 // over 16 lanes (4 rows per wavefront, E = ceil(K / 16) registers), which fills the lanes (K = 100: 89 % as 16 x 7
 // instead of 78 % as 32 x 4; K = 10: 62 % instead of 31 %) and shares the per-row work among more rows.  Measured on
@@ -1751,16 +1758,18 @@ template <int E> struct LaunchMMProbe {
 #ifndef TCLIP_MM_LAUNCH_WAVES
 #define TCLIP_MM_LAUNCH_WAVES 4
 #endif
+enum MMKind { kMMLive = 0, kMMDead = 1, kMMProbe = 2 };
 template <int E, int G>
-static void launch_mm_EG(bool dead, int rows, hipStream_t st, const MMArgs& a) {
+static void launch_mm_EG(int dead, int rows, hipStream_t st, const MMArgs& a) {
     constexpr int kWaves = TCLIP_MM_LAUNCH_WAVES, kRowsPerBlock = (64 / G) * kWaves;
     int grid = (rows + kRowsPerBlock - 1) / kRowsPerBlock;
     if (grid > 256 * 16) grid = 256 * 16;
-    if (dead) hipLaunchKernelGGL((k_mm_live<E, kWaves, true, 1, G>), dim3(grid), dim3(64 * kWaves), 0, st, a);
+    if (dead == kMMProbe) hipLaunchKernelGGL((k_mm_probe<E, G>), dim3(grid), dim3(256), 0, st, a);
+    else if (dead) hipLaunchKernelGGL((k_mm_live<E, kWaves, true, 1, G>), dim3(grid), dim3(64 * kWaves), 0, st, a);
     else hipLaunchKernelGGL((k_mm_live<E, kWaves, false, 1, G>), dim3(grid), dim3(64 * kWaves), 0, st, a);
 }
 template <int G>
-static void launch_mm_G(int need, bool dead, int rows, hipStream_t st, const MMArgs& a) {
+static void launch_mm_G(int need, int dead, int rows, hipStream_t st, const MMArgs& a) {
     if (G < 32 || need <= 8) {
         if (need <= 1) return launch_mm_EG<1, G>(dead, rows, st, a);
         if (need <= 2) return launch_mm_EG<2, G>(dead, rows, st, a);
@@ -1781,7 +1790,7 @@ static void launch_mm_G(int need, bool dead, int rows, hipStream_t st, const MMA
         return launch_mm_EG<32, G>(dead, rows, st, a);
     }
 }
-static void launch_mm(bool dead, int K, int rows, hipStream_t st, const MMArgs& a) {
+static void launch_mm(int dead, int K, int rows, hipStream_t st, const MMArgs& a) {
     const bool wide = g_rowset_min_rows == 0;              // test hook: the 32-lane layout for every row length
 #if TCLIP_G64_MIN_K > 0
     if (K >= TCLIP_G64_MIN_K && K >= 512 && !wide) return launch_mm_EG<16, 64>(dead, rows, st, a);   // 512: the cascade's first dump
@@ -1954,12 +1963,10 @@ static int enqueue_batches(const tclip_problem& p, const float* x_q, const float
             a.has_check = (a.l1 > 0 && a.l1 % 50 == 0) ? 1 : 0;
             a.n_checks = n_checks > 0 ? n_checks : 1;
             a.work_counter = g_prof.on ? g_prof.counter : nullptr;
-            int grid = (TK + 7) / 8;
-            if (grid > 256 * 16) grid = 256 * 16;
             hipEvent_t e0 = g_prof.on ? prof_event() : nullptr, e1 = g_prof.on ? prof_event() : nullptr;
             if (e0 && e1) TCLIP_HIP(hipEventRecord(e0, st));
             a.rows = live_rows; a.n_rows = counts + 1;
-            launch_mm(false, K, TK, st, a);
+            launch_mm(kMMLive, K, TK, st, a);
             if (e0 && e1) TCLIP_HIP(hipEventRecord(e1, st));    // the instrumentation covers k_mm_live only
             if (zs && a.has_check) {          // dead rows only matter through their stop-test terms
                 a.rows = dead_list[c & 1]; a.n_rows = dead_counts + c; a.work_counter = nullptr;
@@ -1969,9 +1976,9 @@ static int enqueue_batches(const tclip_problem& p, const float* x_q, const float
                 int32_t* next_rows = more ? dead_list[(c + 1) & 1] : nullptr;
                 int32_t* next_count = more ? dead_counts + c + 1 : nullptr;
                 a.next_rows = probe ? nullptr : next_rows; a.next_count = probe ? nullptr : next_count;
-                launch_mm(true, K, TK, st, a);
+                launch_mm(kMMDead, K, TK, st, a);
                 a.next_rows = next_rows; a.next_count = next_count;
-                if (probe) dispatch_E<LaunchMMProbe>(K, grid, st, a);
+                if (probe) launch_mm(kMMProbe, K, TK, st, a);
             }
             const bool two_stage = a.has_check && N * K > 16384;
             if (two_stage)
