@@ -18,6 +18,15 @@ timed("K=1000 zero-shot soft, 2 batches x 125 tasks, 20x1000",
 x, _ = synth.make_query_tasks(200, 397, seed=5); x = x.cuda()
 timed("K=397 zero-shot hard, 2 batches x 100 tasks, 10x1000",
       lambda: engine.run_em_dirichlet(x, n_batches=2, iters=10, iter_mm=1000, lambd=79 * 75, hard=True))
+x, _ = synth.make_query_tasks(1000, 397, seed=5); x = x.cuda()
+timed("K=397 zero-shot hard, 10 batches x 100 tasks, 10x1000 (configs[2], first method)",
+      lambda: engine.run_em_dirichlet(x, n_batches=10, iters=10, iter_mm=1000, lambd=79 * 75, hard=True))
+del x
+x, _ = synth.make_query_tasks(100, 1000, seed=5, k_eff=5); xs, ys = synth.make_support(100, 1000, 4, seed=5)
+x, xs, ys = x.cuda(), xs.cuda(), ys.squeeze(2).cuda()
+timed("K=1000 few-shot 4-shot soft, 4 batches x 25 tasks, 20x1000 (configs[4] shape, 100 tasks)",
+      lambda: engine.run_em_dirichlet(x, xs, ys, n_batches=4, iters=20, iter_mm=1000, lambd=200 * 75, hard=False))
+del x, xs, ys
 x, _ = synth.make_query_tasks(100, 100, seed=5, k_eff=5); xs, ys = synth.make_support(100, 100, 4, seed=5)
 x, xs, ys = x.cuda(), xs.cuda(), ys.squeeze(2).cuda()
 timed("K=100 few-shot 4-shot soft, 1 batch x 100 tasks, 20x1000",

@@ -261,6 +261,14 @@ __global__ __launch_bounds__(64) void k_mstats_rows(const float* __restrict__ u,
     const int t = blockIdx.z, k0 = blockIdx.y * kMstatsRows;
     const int d = blockIdx.x * blockDim.x + threadIdx.x;
     if (d >= K) return;
+    {   // nothing is stored for rows that are not live: skip the group when none of its rows is (block-uniform).
+        // After the first E-step most classes of a task are empty (K = 1000: ~40 of 1000 live; the accuracy
+        // tail's one-hot statistics: <= 10 clusters), so most groups end here.
+        bool any = false;
+#pragma unroll
+        for (int j = 0; j < kMstatsRows; j++) any = any || live[(size_t)t * K + k0 + j];
+        if (!any) return;
+    }
     const float* ut = u + (size_t)t * Q * K + k0;
     const float* ft = f + (size_t)t * Q * K + d;
     float wcv[kMstatsRows];
