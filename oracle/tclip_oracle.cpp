@@ -296,14 +296,24 @@ int tclip_oracle_run(const float* z, const float* xs, const int64_t* ys, int N, 
         // ---- convergence record: mean_n ||alpha_old - alpha||_F / ||alpha_old||_F
         float csum = 0;   // torch mean over N floats (N small): sequential is what sum_inner gives below
         std::vector<float> ratios(N);
+        // torch's x.norm(dim=(1,2)): one serial pass, eight fused accumulators by index mod 8, added in order, then the
+        // n mod 8 tail (first four as product + add, the rest fused), one correctly rounded square root
+        auto norm8 = [](const float* x, size_t n) {
+            float acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+            const size_t nv = n & ~(size_t)7;
+            for (size_t d = 0; d < nv; d++) acc[d & 7] = __builtin_fmaf(x[d], x[d], acc[d & 7]);
+            float b = acc[0];
+            for (int l = 1; l < 8; l++) b += acc[l];
+            size_t d = nv;
+            if (n - d >= 4) for (int k = 0; k < 4; k++, d++) b = b + x[d] * x[d];
+            for (; d < n; d++) b = __builtin_fmaf(x[d], x[d], b);
+            return sqrtf(b);
+        };
+        std::vector<float> diff((size_t)K * K);
         for (int n = 0; n < N; n++) {
-            double a = 0, b = 0;
-            for (size_t i = (size_t)n * K * K; i < (size_t)(n + 1) * K * K; i++) {
-                const double dlt = (double)alpha_old[i] - (double)alpha[i];
-                a += dlt * dlt;
-                b += (double)alpha_old[i] * (double)alpha_old[i];
-            }
-            ratios[n] = (float)sqrt(a) / (float)sqrt(b);
+            const size_t off = (size_t)n * K * K;
+            for (size_t i = 0; i < (size_t)K * K; i++) diff[i] = alpha_old[off + i] - alpha[off + i];
+            ratios[n] = norm8(diff.data(), (size_t)K * K) / norm8(&alpha_old[off], (size_t)K * K);
         }
         csum = sum_inner(N, [&](long n) { return ratios[n]; });
         criterions[it] = (few && hard) ? 0.0f : csum / (float)N;

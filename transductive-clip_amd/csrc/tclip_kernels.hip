@@ -1179,32 +1179,60 @@ __global__ __launch_bounds__(256) void k_softmax(const float* logit0, const floa
 }
 
 // ------------------------------------------------------------------------------------------
-// Convergence record (em_dirichlet.py:236-239): per task ||alpha_old - alpha||_F / ||alpha_old||_F,
-// then alpha_old <- alpha.  One block per task, fp64 accumulation.
-__global__ __launch_bounds__(256) void k_criterion(const float* __restrict__ alpha, float* __restrict__ alpha_old, int K,
-                                                   float* __restrict__ ratio) {
-    const int t = blockIdx.x;
-    const size_t n = (size_t)K * K, base = (size_t)t * n;
-    double a = 0.0, b = 0.0;
-    for (size_t i = threadIdx.x; i < n; i += blockDim.x) {
-        const float o = alpha_old[base + i], c = alpha[base + i];
-        const double d = (double)o - (double)c;
-        a += d * d;
-        b += (double)o * (double)o;
-        alpha_old[base + i] = c;
-    }
-    __shared__ double sh[2][256];
-    sh[0][threadIdx.x] = a;
-    sh[1][threadIdx.x] = b;
-    __syncthreads();
-    for (int s = blockDim.x / 2; s > 0; s >>= 1) {
-        if ((int)threadIdx.x < s) {
-            sh[0][threadIdx.x] += sh[0][threadIdx.x + s];
-            sh[1][threadIdx.x] += sh[1][threadIdx.x + s];
+// Convergence record (em_dirichlet.py:236-239): per task ||alpha_old - alpha||_F / ||alpha_old||_F, then
+// alpha_old <- alpha, with torch's fp32 norm: `x.norm(dim=(1,2))` is ONE serial pass over the task's K*K elements
+// with eight fused multiply-add accumulators by element index mod 8, the accumulators added in order, the n mod 8
+// tail (first four as product + add, the rest fused), one correctly rounded square root (probed bit for bit up to
+// 10^6 elements, oracle/mathcheck.cpp::mc_norm8).  One wavefront per task: 64 consecutive elements per step, lane j < 8
+// owns accumulator j and takes its eight operands of the step from lanes j, 8 + j, ..., 56 + j in order.
+__global__ __launch_bounds__(64) void k_criterion(const float* __restrict__ alpha, float* __restrict__ alpha_old, int K,
+                                                  float* __restrict__ ratio) {
+    const int t = blockIdx.x, lane = threadIdx.x, j = lane & 7;
+    const size_t n = (size_t)K * K, base = (size_t)t * n, nv = n & ~(size_t)7;
+    float acc_d = 0.0f, acc_o = 0.0f;                         // meaningful in lanes 0..7
+    size_t s0 = 0;
+    for (; s0 + 64 <= nv; s0 += 64) {
+        const float o = alpha_old[base + s0 + lane], c = alpha[base + s0 + lane];
+        const float d = o - c;
+        alpha_old[base + s0 + lane] = c;
+#pragma unroll
+        for (int i = 0; i < 8; i++) {
+            const float vd = __shfl(d, 8 * i + j, 64), vo = __shfl(o, 8 * i + j, 64);
+            acc_d = __builtin_fmaf(vd, vd, acc_d);
+            acc_o = __builtin_fmaf(vo, vo, acc_o);
         }
-        __syncthreads();
     }
-    if (threadIdx.x == 0) ratio[t] = (float)__builtin_sqrt(sh[0][0]) / (float)__builtin_sqrt(sh[1][0]);
+    {   // the last, partial step: the rest of the whole 8-element groups and the n mod 8 tail (< 64 elements together)
+        const size_t i0 = s0 + lane;
+        const bool in = i0 < n;
+        const float o = in ? alpha_old[base + i0] : 0.0f, c = in ? alpha[base + i0] : 0.0f;
+        const float d = o - c;
+        if (in) alpha_old[base + i0] = c;
+        const int groups = (int)((nv - s0) >> 3);             // wave-uniform, 0..7
+        for (int i = 0; i < groups; i++) {
+            const float vd = __shfl(d, 8 * i + j, 64), vo = __shfl(o, 8 * i + j, 64);
+            acc_d = __builtin_fmaf(vd, vd, acc_d);
+            acc_o = __builtin_fmaf(vo, vo, acc_o);
+        }
+        float bd = __shfl(acc_d, 0, 64), bo = __shfl(acc_o, 0, 64);
+#pragma unroll
+        for (int l = 1; l < 8; l++) {
+            bd += __shfl(acc_d, l, 64);
+            bo += __shfl(acc_o, l, 64);
+        }
+        const int ntail = (int)(n - nv), tail0 = 8 * groups;  // the tail sits in lanes tail0 .. tail0 + ntail - 1
+        for (int k = 0; k < ntail; k++) {
+            const float vd = __shfl(d, tail0 + k, 64), vo = __shfl(o, tail0 + k, 64);
+            if (ntail >= 4 && k < 4) {                        // the vectorised epilogue: product, then add
+                bd = bd + vd * vd;
+                bo = bo + vo * vo;
+            } else {
+                bd = __builtin_fmaf(vd, vd, bd);
+                bo = __builtin_fmaf(vo, vo, bo);
+            }
+        }
+        if (lane == 0) ratio[t] = __builtin_sqrtf(bd) / __builtin_sqrtf(bo);
+    }
 }
 
 __global__ void k_criterion_mean(const float* __restrict__ ratio, int N, int force_zero, float* __restrict__ out, int stride) {
@@ -2008,7 +2036,7 @@ static int enqueue_batches(const tclip_problem& p, const float* x_q, const float
         hipLaunchKernelGGL(k_softmax, dim3((T * Q * 16 + 255) / 256), dim3(256), 0, st, (const float*)logit0, (const float*)v,
                            T * Q, Q, K, (float)p.lambd, p.hard, 0, u, preds);
         // ---- convergence record
-        hipLaunchKernelGGL(k_criterion, dim3(T), dim3(256), 0, st, (const float*)alpha, alpha_old, K, ratio);
+        hipLaunchKernelGGL(k_criterion, dim3(T), dim3(64), 0, st, (const float*)alpha, alpha_old, K, ratio);
         hipLaunchKernelGGL(k_criterion_mean, dim3(B), dim3(64), 0, st, (const float*)ratio, N, (!zs && p.hard) ? 1 : 0,
                            criterions + it, p.iters);
     }
