@@ -151,6 +151,7 @@ def roofline_of(prof, steps, K, pmc_key):
            "flop_eq_per_element_update": FLOP_EQ_PER_UPDATE,
            "element_updates_executed_per_step": updates / steps,
            "element_updates_per_s": updates / (mm_ms * 1e-3) if mm_ms > 0 else 0.0,
+           "element_updates_per_launch": updates / max(mm_launches, 1),
            "kernel_busy_ms_per_step": mm_ms / steps, "launches_per_step": mm_launches / steps,
            "avg_launch_ms": mm_launch_sum / max(mm_launches, 1),
            "launch_overlap": mm_launch_sum / mm_ms if mm_ms > 0 else 0.0,
