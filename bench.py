@@ -176,6 +176,8 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-secondary", action="store_true")
     ap.add_argument("--workload", choices=["k1000", "k100"], default="k1000", help="headline workload (k100: round-1 shape)")
+    ap.add_argument("--backend", default="nccl", help="process-group backend (nccl = RCCL; gloo only to test the N>1 path on one GPU)")
+    ap.add_argument("--single-device", action="store_true", help="testing: every rank uses cuda:0")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -184,11 +186,16 @@ def main():
     dist_on = "RANK" in os.environ          # launched by torch.distributed.run (any world size)
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the EM-Dirichlet engine has no CPU path")
+    if args.single_device:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     if dist_on:
         import torch.distributed as dist
-        dist.init_process_group("nccl", device_id=dev)
+        if args.backend == "nccl":
+            dist.init_process_group("nccl", device_id=dev)
+        else:
+            dist.init_process_group(args.backend)
 
     import random
 
@@ -228,7 +235,7 @@ def main():
         prof = engine.profile_collect()
         engine.profile_enable(False)
         if dist_on:
-            t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+            t = torch.tensor([elapsed], device=dev if args.backend == "nccl" else "cpu", dtype=torch.float64)
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
             elapsed = float(t.item())
         return elapsed, prof, acc_mean

@@ -193,3 +193,24 @@ def test_engine_matches_torch_digests(c):
     assert r.mm_iters[0].cpu().tolist() == c["mm_iters"]
     assert _sha(r.alpha.cpu().numpy()) == c["alpha"], "alpha differs from torch's"
     assert _sha(r.u.cpu().numpy()) == c["u"] and _sha(r.v.cpu().numpy()) == c["v"]
+
+
+def test_bench_multi_rank_path_on_one_gpu():
+    """bench.py under the driver's launcher with TWO ranks (gloo for the collective, both ranks on cuda:0 - there is
+    one GPU here): the N > 1 code path end to end - same index stream on both ranks, round-robin batches, one
+    gather, max-over-ranks time, one JSON line from rank 0 with the work of both ranks."""
+    import subprocess
+    import sys
+    from conftest import ROOT
+    port = 29700 + os.getpid() % 200
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "1",
+           "--workload", "k100", "--backend", "gloo", "--single-device"]
+    out = subprocess.run(cmd, capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stderr[-2000:]
+    lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, out.stdout[-2000:]
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["scaling"] == "weak" and d["config"]["tasks_total"] == 2000
+    assert d["value"] > 0 and abs(d["value"] - 2000 / (d["ms_per_step"] * 1e-3)) < 1e-6 * d["value"]
+    assert 0.5 < d["config"]["mean_accuracy"] < 1.0 and "roofline" in d and "cpu_baseline" not in d
