@@ -1184,23 +1184,48 @@ __global__ __launch_bounds__(256) void k_softmax(const float* logit0, const floa
 // with eight fused multiply-add accumulators by element index mod 8, the accumulators added in order, the n mod 8
 // tail (first four as product + add, the rest fused), one correctly rounded square root (probed bit for bit up to
 // 10^6 elements, oracle/mathcheck.cpp::mc_norm8).  One wavefront per task: 64 consecutive elements per step, lane j < 8
-// owns accumulator j and takes its eight operands of the step from lanes j, 8 + j, ..., 56 + j in order.
-__global__ __launch_bounds__(64) void k_criterion(const float* __restrict__ alpha, float* __restrict__ alpha_old, int K,
+// owns accumulator j and takes its eight operands of the step from lanes j, 8 + j, ..., 56 + j in order; eight steps of
+// loads are in flight at a time (the chain of n/8 dependent FMAs per accumulator is inherent, the kernel lives on
+// memory latency; a variant with four tasks per wavefront and DPP operands had a quarter of the wavefronts and was slower).
+__global__ __launch_bounds__(64) void k_criterion(const float* __restrict__ alpha, float* __restrict__ alpha_old, int K, int T,
                                                   float* __restrict__ ratio) {
     const int t = blockIdx.x, lane = threadIdx.x, j = lane & 7;
+    if (t >= T) return;
     const size_t n = (size_t)K * K, base = (size_t)t * n, nv = n & ~(size_t)7;
     float acc_d = 0.0f, acc_o = 0.0f;                         // meaningful in lanes 0..7
-    size_t s0 = 0;
-    for (; s0 + 64 <= nv; s0 += 64) {
-        const float o = alpha_old[base + s0 + lane], c = alpha[base + s0 + lane];
+    auto step = [&](float o, float c, int groups) {           // `groups` whole groups of eight elements, in order
         const float d = o - c;
-        alpha_old[base + s0 + lane] = c;
-#pragma unroll
-        for (int i = 0; i < 8; i++) {
+        for (int i = 0; i < groups; i++) {
             const float vd = __shfl(d, 8 * i + j, 64), vo = __shfl(o, 8 * i + j, 64);
             acc_d = __builtin_fmaf(vd, vd, acc_d);
             acc_o = __builtin_fmaf(vo, vo, acc_o);
         }
+    };
+    size_t s0 = 0;
+    constexpr int kDepth = 8;
+    for (; s0 + 64 * kDepth <= nv; s0 += 64 * kDepth) {
+        float o[kDepth], c[kDepth];
+#pragma unroll
+        for (int k = 0; k < kDepth; k++) {
+            o[k] = alpha_old[base + s0 + 64 * k + lane];
+            c[k] = alpha[base + s0 + 64 * k + lane];
+        }
+#pragma unroll
+        for (int k = 0; k < kDepth; k++) {
+            alpha_old[base + s0 + 64 * k + lane] = c[k];
+#pragma unroll
+            for (int i = 0; i < 8; i++) {
+                const float d = o[k] - c[k];
+                const float vd = __shfl(d, 8 * i + j, 64), vo = __shfl(o[k], 8 * i + j, 64);
+                acc_d = __builtin_fmaf(vd, vd, acc_d);
+                acc_o = __builtin_fmaf(vo, vo, acc_o);
+            }
+        }
+    }
+    for (; s0 + 64 <= nv; s0 += 64) {
+        const float o = alpha_old[base + s0 + lane], c = alpha[base + s0 + lane];
+        alpha_old[base + s0 + lane] = c;
+        step(o, c, 8);
     }
     {   // the last, partial step: the rest of the whole 8-element groups and the n mod 8 tail (< 64 elements together)
         const size_t i0 = s0 + lane;
@@ -1209,11 +1234,7 @@ __global__ __launch_bounds__(64) void k_criterion(const float* __restrict__ alph
         const float d = o - c;
         if (in) alpha_old[base + i0] = c;
         const int groups = (int)((nv - s0) >> 3);             // wave-uniform, 0..7
-        for (int i = 0; i < groups; i++) {
-            const float vd = __shfl(d, 8 * i + j, 64), vo = __shfl(o, 8 * i + j, 64);
-            acc_d = __builtin_fmaf(vd, vd, acc_d);
-            acc_o = __builtin_fmaf(vo, vo, acc_o);
-        }
+        step(o, c, groups);
         float bd = __shfl(acc_d, 0, 64), bo = __shfl(acc_o, 0, 64);
 #pragma unroll
         for (int l = 1; l < 8; l++) {
@@ -2036,7 +2057,7 @@ static int enqueue_batches(const tclip_problem& p, const float* x_q, const float
         hipLaunchKernelGGL(k_softmax, dim3((T * Q * 16 + 255) / 256), dim3(256), 0, st, (const float*)logit0, (const float*)v,
                            T * Q, Q, K, (float)p.lambd, p.hard, 0, u, preds);
         // ---- convergence record
-        hipLaunchKernelGGL(k_criterion, dim3(T), dim3(64), 0, st, (const float*)alpha, alpha_old, K, ratio);
+        hipLaunchKernelGGL(k_criterion, dim3(T), dim3(64), 0, st, (const float*)alpha, alpha_old, K, T, ratio);
         hipLaunchKernelGGL(k_criterion_mean, dim3(B), dim3(64), 0, st, (const float*)ratio, N, (!zs && p.hard) ? 1 : 0,
                            criterions + it, p.iters);
     }
