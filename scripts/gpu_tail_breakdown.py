@@ -1,0 +1,39 @@
+"""Accuracy tail at K=1000, 1250 tasks: where the time goes"""
+import os, sys, time, ctypes
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "transductive-clip_amd"))
+import torch
+from tclip_amd import engine, synth, _capi
+from tclip_amd.engine import _ptr, _stream
+T, Q, K = 1250, 75, 1000
+feats, labels = synth.make_feature_table(K, 50, seed=2020)
+g = torch.Generator().manual_seed(1)
+idx = torch.randint(0, feats.shape[0], (T * Q,), generator=g)
+x_q = feats[idx].view(T, Q, K).cuda(); y_q = labels[idx].view(T, Q)
+preds = torch.stack([torch.randint(0, K, (8,), generator=g)[torch.randint(0, 8, (Q,), generator=g)] for _ in range(T)]).int().cuda()
+lib = _capi.lib()
+if len(sys.argv) > 1:      # with the engine run in front, as in a bench step
+    res = engine.run_em_dirichlet(x_q, n_batches=10, iters=2, iter_mm=60, lambd=200 * 75)
+    preds = res.preds
+    torch.cuda.synchronize()
+def sync(): torch.cuda.synchronize(); return time.perf_counter()
+for rep in range(3):
+    if len(sys.argv) > 1:
+        res = engine.run_em_dirichlet(x_q, n_batches=10, iters=2, iter_mm=60, lambd=200 * 75); preds = res.preds
+    t0 = sync()
+    cmax = min(Q, K)
+    ws_bytes = lib.tclip_prototype_workspace_bytes(T, Q, K)
+    ws = torch.empty(ws_bytes + 256, dtype=torch.uint8, device="cuda"); off = (-ws.data_ptr()) % 256
+    n_clusters = torch.empty(T, dtype=torch.int32, device="cuda"); ids = torch.empty(T, cmax, dtype=torch.int32, device="cuda")
+    protos = torch.empty(T, cmax, K, device="cuda")
+    t1 = sync()
+    rc = lib.tclip_cluster_prototypes(T, Q, K, _ptr(x_q), _ptr(preds), _ptr(n_clusters), _ptr(ids), _ptr(protos), ctypes.c_void_p(ws.data_ptr() + off), ws_bytes, _stream())
+    t2 = sync()
+    preds_h, nc_h = preds.cpu(), n_clusters.cpu(); used = int(nc_h.max())
+    ids_h, protos_h = ids[:, :used].contiguous().cpu(), protos[:, :used].contiguous().cpu()
+    t3 = sync()
+    y_h = y_q.long().contiguous(); new_preds = torch.empty(T, Q, dtype=torch.int32); acc = torch.empty(T)
+    rc = lib.tclip_match_clusters_host_strided(T, Q, K, _ptr(preds_h), _ptr(nc_h), _ptr(ids_h), _ptr(protos_h), _ptr(y_h), 1, used, _ptr(new_preds), _ptr(acc))
+    t4 = sync()
+    print(f"alloc {1e3*(t1-t0):.1f} ms  device prototypes {1e3*(t2-t1):.1f}  copies {1e3*(t3-t2):.1f} (used={used})  host matching {1e3*(t4-t3):.1f}")

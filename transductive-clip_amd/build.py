@@ -33,7 +33,7 @@ def up_to_date():
 def build(force=False, verbose=False):
     if not force and up_to_date():
         return OUT
-    cmd = [hipcc(), "--offload-arch=gfx950", "-O3", "-ffp-contract=off", "-fPIC", "-shared", "-std=c++17",
+    cmd = [hipcc(), "--offload-arch=gfx950", "-O3", "-ffp-contract=off", "-fPIC", "-shared", "-pthread", "-std=c++17",
            "-Wall", "-Wno-unused-function", "-o", OUT] + [os.path.join(CSRC, s) for s in SOURCES]
     if verbose:
         print(" ".join(cmd), flush=True)

@@ -11,7 +11,10 @@
 #include <stdint.h>
 #include <string.h>
 
+#include <stdlib.h>
+
 #include <algorithm>
+#include <thread>
 #include <vector>
 
 #include "../../include/tclip.h"
@@ -82,17 +85,15 @@ extern "C" int tclip_match_clusters_host(int32_t T, int32_t Q, int32_t K, const 
                                              Q < K ? Q : K, new_preds, acc);
 }
 
-extern "C" int tclip_match_clusters_host_strided(int32_t T, int32_t Q, int32_t K, const int32_t* preds,
-                                                 const int32_t* n_clusters, const int32_t* cluster_ids,
-                                                 const float* prototypes, const int64_t* y_q, int32_t graph_matching,
-                                                 int32_t c_stride, int32_t* new_preds, float* acc) {
-    if (T < 1 || Q < 1 || K < 2 || !preds || !n_clusters || !cluster_ids || !prototypes || !y_q || !new_preds || !acc)
-        return TCLIP_ERR_ARG;
-    const int Cmax = c_stride;
-    if (Cmax < 1 || Cmax > (Q < K ? Q : K)) return TCLIP_ERR_ARG;
+namespace {
+
+// tasks t0 .. t1-1; returns TCLIP_OK or the first error
+int match_range(int t0, int t1, int Q, int K, int Cmax, const int32_t* preds, const int32_t* n_clusters,
+                const int32_t* cluster_ids, const float* prototypes, const int64_t* y_q, int graph_matching,
+                int32_t* new_preds, float* acc) {
     std::vector<double> cost;
     std::vector<int> col_of_row, lut(K);
-    for (int t = 0; t < T; t++) {
+    for (int t = t0; t < t1; t++) {
         const int C = n_clusters[t];
         if (C < 1 || C > Cmax) return TCLIP_ERR_ARG;
         const int32_t* ids = cluster_ids + (size_t)t * Cmax;
@@ -126,5 +127,40 @@ extern "C" int tclip_match_clusters_host_strided(int32_t T, int32_t Q, int32_t K
         // torch: (new == y).float().mean(1): sum of 0/1 floats (exact) divided by Q in fp32
         acc[t] = (float)hit / (float)Q;
     }
+    return TCLIP_OK;
+}
+
+}  // namespace
+
+// Tasks are independent: large batches are matched by a few host threads (the K = 1000 bench step spent 150 ms
+// here on one thread, 1.2 % of the step).  TCLIP_HOST_THREADS overrides the count (default: up to 16).
+extern "C" int tclip_match_clusters_host_strided(int32_t T, int32_t Q, int32_t K, const int32_t* preds,
+                                                 const int32_t* n_clusters, const int32_t* cluster_ids,
+                                                 const float* prototypes, const int64_t* y_q, int32_t graph_matching,
+                                                 int32_t c_stride, int32_t* new_preds, float* acc) {
+    if (T < 1 || Q < 1 || K < 2 || !preds || !n_clusters || !cluster_ids || !prototypes || !y_q || !new_preds || !acc)
+        return TCLIP_ERR_ARG;
+    const int Cmax = c_stride;
+    if (Cmax < 1 || Cmax > (Q < K ? Q : K)) return TCLIP_ERR_ARG;
+    int n_threads = 16;
+    if (const char* e = getenv("TCLIP_HOST_THREADS")) n_threads = atoi(e);
+    const int hw = (int)std::thread::hardware_concurrency();
+    if (hw > 0 && n_threads > hw) n_threads = hw;
+    const long work = (long)T * K;                             // below ~8 k cost-matrix columns per thread a thread is not worth starting
+    if (n_threads > work / 8192) n_threads = (int)(work / 8192);
+    if (n_threads > T) n_threads = T;
+    if (n_threads <= 1)
+        return match_range(0, T, Q, K, Cmax, preds, n_clusters, cluster_ids, prototypes, y_q, graph_matching, new_preds, acc);
+    std::vector<int> rc(n_threads, TCLIP_OK);
+    std::vector<std::thread> pool;
+    for (int i = 0; i < n_threads; i++) {
+        const int t0 = (int)((long)T * i / n_threads), t1 = (int)((long)T * (i + 1) / n_threads);
+        pool.emplace_back([=, &rc] {
+            rc[i] = match_range(t0, t1, Q, K, Cmax, preds, n_clusters, cluster_ids, prototypes, y_q, graph_matching, new_preds, acc);
+        });
+    }
+    for (auto& th : pool) th.join();
+    for (int i = 0; i < n_threads; i++)
+        if (rc[i] != TCLIP_OK) return rc[i];
     return TCLIP_OK;
 }

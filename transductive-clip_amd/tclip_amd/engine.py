@@ -214,7 +214,12 @@ def clustering_accuracy(x_q, preds, y_q, graph_matching=True):
         _capi.check(rc, "tclip_cluster_prototypes")
         preds_h, nc_h = preds.cpu(), n_clusters.cpu()
         used = max(1, min(cmax, int(nc_h.max())))          # rows of the fullest task: only those travel to the host
-        ids_h, protos_h = ids[:, :used].contiguous().cpu(), protos[:, :used].contiguous().cpu()
+        # page-locked staging buffers (torch caches them): the prototype block is the one sizeable device-to-host copy of a step
+        ids_h = torch.empty((T, used), dtype=torch.int32, pin_memory=True)
+        protos_h = torch.empty((T, used, K), dtype=torch.float32, pin_memory=True)
+        ids_h.copy_(ids[:, :used], non_blocking=True)
+        protos_h.copy_(protos[:, :used], non_blocking=True)
+        torch.cuda.current_stream().synchronize()
     y_h = y_q.reshape(T, Q).long().cpu().contiguous()
     new_preds = torch.empty(T, Q, dtype=torch.int32)
     acc = torch.empty(T, dtype=torch.float32)
