@@ -43,9 +43,27 @@ namespace tclip {
 
 // ------------------------------------------------------------------------------------------
 // element-wise log of the features: log(x + 1e-15)                      (em_dirichlet.py:38)
-__global__ void k_log_features(const float* __restrict__ x, float* __restrict__ out, size_t n) {
-    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x)
-        out[i] = log_f32(x[i] + kEpsF);
+// `nonfinite` (optional) is raised when some log is NaN or infinite (features off the simplex).
+__global__ void k_log_features(const float* __restrict__ x, float* __restrict__ out, size_t n, int32_t* __restrict__ nonfinite) {
+    bool bad = false;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+        const float v = log_f32(x[i] + kEpsF);
+        out[i] = v;
+        bad = bad || (f32_bits(v) & 0x7f800000u) == 0x7f800000u;
+    }
+    if (nonfinite && bad) atomicOr(nonfinite, 1);
+}
+
+// The E-step terms of the initial alpha = 1: (alpha - 1) . log z is a sum of zeros, +0 in torch's order whenever every
+// log z is finite, so logit0[t,q,k] = rowc[t,k] + 0 = rowc[t,k] - a fill instead of T*K*Q dot products of length K
+// (K = 1000, 417 tasks: 75 ms per call).  With a non-finite log z (0 * inf = NaN) the general kernel runs instead.
+__global__ void k_init_logits(const float* __restrict__ rowc, const int32_t* __restrict__ nonfinite, int Q, int K, size_t n,
+                              float* __restrict__ logit0) {
+    if (*nonfinite) return;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+        const size_t t = i / ((size_t)Q * K);
+        logit0[i] = rowc[t * K + i % K] + 0.0f;
+    }
 }
 
 __global__ void k_fill(float* __restrict__ p, float v, size_t n) {
@@ -977,7 +995,8 @@ template <int E>
 __global__ __launch_bounds__(256) void k_logits(const float* __restrict__ alpha, const float* __restrict__ logz,
                                                 const float* __restrict__ rowc, const int32_t* __restrict__ rows,
                                                 const int32_t* __restrict__ n_rows, int Q, int K,
-                                                float* __restrict__ logit0) {
+                                                float* __restrict__ logit0, const int32_t* __restrict__ only_if) {
+    if (only_if && *only_if == 0) return;           // the initial call: k_init_logits has done the work
     const int lane = threadIdx.x & (kGroup - 1);
     const int group = threadIdx.x / kGroup, groups_per_block = blockDim.x / kGroup;
     const int n = *n_rows;
@@ -1725,7 +1744,7 @@ static hipEvent_t prof_event() {
 constexpr int kDecideSlices = 64;     // blocks per batch in the first stage of the stop test (large batches)
 struct Layout {
     size_t logz, y, alpha_old, beta_dead, sup, cnt, cs, live, rowc, logit0, cache, cache_len, rowpart, mm_rows,
-        mm_rows2, dead_counts, live_rows, counts, stop, ratio, dpart, total;
+        mm_rows2, dead_counts, live_rows, counts, flags, stop, ratio, dpart, total;
     int n_checks;
 };
 
@@ -1757,6 +1776,7 @@ static Layout make_layout(const tclip_problem& p) {
     L.dead_counts = take(((size_t)n_chunks_of(p.iter_mm) + 2) * 4);
     L.live_rows = take(T * K * 4);
     L.counts = take(256);
+    L.flags = take(256);
     L.stop = take((size_t)p.n_batches * 4);
     L.ratio = take(T * 4);
     L.dpart = take((size_t)p.n_batches * kDecideSlices * 2 * sizeof(double));
@@ -1865,8 +1885,8 @@ template <int E> struct LaunchRowConsts {
 };
 template <int E> struct LaunchLogits {
     static void run(int grid, hipStream_t st, const float* alpha, const float* logz, const float* rowc,
-                    const int32_t* rows, const int32_t* n, int Q, int K, float* logit0) {
-        hipLaunchKernelGGL(k_logits<E>, dim3(grid), dim3(256), 0, st, alpha, logz, rowc, rows, n, Q, K, logit0);
+                    const int32_t* rows, const int32_t* n, int Q, int K, float* logit0, const int32_t* only_if) {
+        hipLaunchKernelGGL(k_logits<E>, dim3(grid), dim3(256), 0, st, alpha, logz, rowc, rows, n, Q, K, logit0, only_if);
     }
 };
 
@@ -1965,6 +1985,7 @@ static int enqueue_batches(const tclip_problem& p, const float* x_q, const float
     int32_t* dead_counts = (int32_t*)(ws + L.dead_counts);                        // [chunk] length of that list
     int32_t* live_rows = (int32_t*)(ws + L.live_rows);
     int32_t* counts = (int32_t*)(ws + L.counts);
+    int32_t* flags = (int32_t*)(ws + L.flags);          // [0]: some log z is not finite
     int32_t* stop = (int32_t*)(ws + L.stop);
     float* ratio = (float*)(ws + L.ratio);
     double* dpart = (double*)(ws + L.dpart);
@@ -1972,7 +1993,8 @@ static int enqueue_batches(const tclip_problem& p, const float* x_q, const float
     const int n_checks = zs ? L.n_checks : 0;   // few-shot has no dead rows: nothing to cache
 
     // ---- initialisation (em_dirichlet.py:195-211)
-    hipLaunchKernelGGL(k_log_features, dim3(ew_grid(TQK)), dim3(256), 0, st, x_q, logz, TQK);
+    TCLIP_HIP(hipMemsetAsync(flags, 0, 256, st));
+    hipLaunchKernelGGL(k_log_features, dim3(ew_grid(TQK)), dim3(256), 0, st, x_q, logz, TQK, flags);
     hipLaunchKernelGGL(k_copy, dim3(ew_grid(TQK)), dim3(256), 0, st, x_q, u, TQK);
     hipLaunchKernelGGL(k_fill, dim3(ew_grid(TKK)), dim3(256), 0, st, alpha, 1.0f, TKK);
     hipLaunchKernelGGL(k_fill, dim3(ew_grid(TKK)), dim3(256), 0, st, alpha_old, 1.0f, TKK);
@@ -1994,8 +2016,9 @@ static int enqueue_batches(const tclip_problem& p, const float* x_q, const float
         TCLIP_HIP(hipMemsetAsync(live, 1, (size_t)TK, st));
         hipLaunchKernelGGL(k_build_rows, dim3((TK + 255) / 256), dim3(256), 0, st, live, cache_len, TK, 0, mm_rows,
                            live_rows, counts, counts + 1);
+        hipLaunchKernelGGL(k_init_logits, dim3(ew_grid(TQK)), dim3(256), 0, st, (const float*)rowc, (const int32_t*)flags, Q, K, TQK, logit0);
         dispatch_E<LaunchLogits>(K, TK > 262144 ? 262144 : TK, st, (const float*)alpha, (const float*)logz, (const float*)rowc,
-                                 (const int32_t*)live_rows, (const int32_t*)(counts + 1), Q, K, logit0);
+                                 (const int32_t*)live_rows, (const int32_t*)(counts + 1), Q, K, logit0, (const int32_t*)flags);
     }
 
     for (int it = 0; it < p.iters; it++) {
@@ -2052,7 +2075,7 @@ static int enqueue_batches(const tclip_problem& p, const float* x_q, const float
             dispatch_E<LaunchRowConsts>(K, g8 > 4096 ? 4096 : g8, st, (const float*)alpha, (const int32_t*)live_rows,
                                         (const int32_t*)(counts + 1), K, rowc);
             dispatch_E<LaunchLogits>(K, TK > 16384 ? 16384 : TK, st, (const float*)alpha, (const float*)logz, (const float*)rowc,
-                                     (const int32_t*)live_rows, (const int32_t*)(counts + 1), Q, K, logit0);
+                                     (const int32_t*)live_rows, (const int32_t*)(counts + 1), Q, K, logit0, (const int32_t*)nullptr);
         }
         hipLaunchKernelGGL(k_softmax, dim3((T * Q * 16 + 255) / 256), dim3(256), 0, st, (const float*)logit0, (const float*)v,
                            T * Q, Q, K, (float)p.lambd, p.hard, 0, u, preds);
