@@ -353,15 +353,28 @@ __global__ __launch_bounds__(64) void k_mstats_rows(const float* __restrict__ u,
 // Row lists for one outer iteration.  live_rows: rows whose alpha will change (k_mm_live iterates
 // them, and their E-step terms must be recomputed); dead_rows: dead rows whose cached stop-test
 // terms are incomplete (k_mm_live<.., true> iterates them).  Order inside the lists is irrelevant to the results.
+__device__ __forceinline__ int lanes_below_mask(unsigned long long m, int lane) { return __popcll(m & ((1ull << lane) - 1ull)); }
+
 __global__ void k_build_rows(const uint8_t* __restrict__ live, const int32_t* __restrict__ cache_len, int n_rows,
                              int n_checks, int32_t* __restrict__ dead_rows, int32_t* __restrict__ live_rows,
                              int32_t* __restrict__ n_dead, int32_t* __restrict__ n_live) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n_rows) return;
-    const bool alive = live[i];
-    const bool need = !alive && n_checks > 0 && cache_len[i] < n_checks;
-    if (need) dead_rows[atomicAdd(n_dead, 1)] = i;
-    if (alive) live_rows[atomicAdd(n_live, 1)] = i;
+    const bool in = i < n_rows;
+    const bool alive = in && live[i];
+    const bool need = in && !alive && n_checks > 0 && cache_len[i] < n_checks;
+    // one atomic per wavefront and list: the 64 consecutive rows of a wavefront (same task, neighbouring classes) stay
+    // together in the lists, so the kernels that sweep them touch the task's log z and y while they are in L2
+    const unsigned long long ml = __ballot(alive), md = __ballot(need);
+    const int lane64 = threadIdx.x & 63;
+    int base_l = 0, base_d = 0;
+    if (lane64 == 0) {
+        if (ml) base_l = atomicAdd(n_live, __popcll(ml));
+        if (md) base_d = atomicAdd(n_dead, __popcll(md));
+    }
+    base_l = __shfl(base_l, 0, 64);
+    base_d = __shfl(base_d, 0, 64);
+    if (alive) live_rows[base_l + lanes_below_mask(ml, lane64)] = i;
+    if (need) dead_rows[base_d + lanes_below_mask(md, lane64)] = i;
 }
 
 // ------------------------------------------------------------------------------------------
