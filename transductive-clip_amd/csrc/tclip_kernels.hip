@@ -1025,12 +1025,16 @@ __global__ __launch_bounds__(256) void k_logits(const float* __restrict__ alpha,
         const float rc = rowc[row];
         for (int q = group; q < Q; q += groups_per_block) {
             const float* lz = logz + ((size_t)t * Q + q) * K;
-            float pr[E];
+            // every load unconditional (index clamped into the row) so that they form one batch in flight; the select
+            // comes afterwards
+            float lv[E], pr[E];
 #pragma unroll
             for (int e = 0; e < E; e++) {
                 const int d = e * kGroup + lane;
-                pr[e] = d < K ? am1[e] * lz[d] : 0.0f;
+                lv[e] = lz[d < K ? d : K - 1];
             }
+#pragma unroll
+            for (int e = 0; e < E; e++) pr[e] = e * kGroup + lane < K ? am1[e] * lv[e] : 0.0f;
             const float l3 = group_sum_torch<E>(pr, K, lane);
             if (lane == 0) logit0[((size_t)t * Q + q) * K + k] = rc + l3;
         }
@@ -1069,10 +1073,12 @@ __global__ __launch_bounds__(256) void k_kmeans_logits_rows(const float* __restr
         const float* zq = z + ((size_t)t * Q + q) * K;
         float zv[E];
 #pragma unroll
-        for (int e = 0; e < E; e++) {
+        for (int e = 0; e < E; e++) {                                   // unconditional loads (index clamped into the row): one batch in flight
             const int d = e * kGroup + lane;
-            zv[e] = d < K ? zq[d] : 0.0f;
+            zv[e] = zq[d < K ? d : K - 1];
         }
+#pragma unroll
+        for (int e = 0; e < E; e++) zv[e] = e * kGroup + lane < K ? zv[e] : 0.0f;
 #pragma unroll
         for (int j = 0; j < kRowsPerBlock; j++) {
             if (!want[j]) continue;                                  // block-uniform
@@ -1121,10 +1127,12 @@ __global__ __launch_bounds__(256) void k_cov_logits_rows(const float* __restrict
         const float* zq = z + ((size_t)t * Q + q) * K;
         float zv[E];
 #pragma unroll
-        for (int e = 0; e < E; e++) {
+        for (int e = 0; e < E; e++) {                                   // unconditional loads (index clamped into the row): one batch in flight
             const int d = e * kGroup + lane;
-            zv[e] = d < K ? zq[d] : 0.0f;
+            zv[e] = zq[d < K ? d : K - 1];
         }
+#pragma unroll
+        for (int e = 0; e < E; e++) zv[e] = e * kGroup + lane < K ? zv[e] : 0.0f;
 #pragma unroll
         for (int j = 0; j < kRowsPerBlock; j++) {
             if (!want[j]) continue;                                  // block-uniform
@@ -1456,9 +1464,13 @@ __global__ __launch_bounds__(256) void k_kl_divergences(const float* __restrict_
         float pv[E];
         bool p_in = true;
 #pragma unroll
-        for (int e = 0; e < E; e++) {
+        for (int e = 0; e < E; e++) {                                   // unconditional loads (index clamped): one batch in flight
             const int d = e * kGroup + lane;
-            pv[e] = d < K ? zq[d] + kEpsF : 1.0f;
+            pv[e] = zq[d < K ? d : K - 1];
+        }
+#pragma unroll
+        for (int e = 0; e < E; e++) {
+            pv[e] = e * kGroup + lane < K ? pv[e] + kEpsF : 1.0f;
             p_in = p_in && fast_range_f32(pv[e]);
         }
         const bool fast = q_ok && __all(p_in);                       // wave-uniform
@@ -1834,6 +1846,9 @@ static void dispatch_E(int K, Args... args) {
 // 1000 tasks (MM loop, 32 -> 16 lanes): K = 10 95 -> 71 ms, K = 37 186 -> 151, K = 47 217 -> 174, K = 100 476 -> 411
 // (460 with round 1's two rows per 32-lane group), K = 196 974 -> 895.  g_rowset_min_rows == 0 (test hook) forces the
 // 32-lane layout, which must give the same bits.
+#ifndef TCLIP_LOGITS_GRID
+#define TCLIP_LOGITS_GRID 16384
+#endif
 #ifndef TCLIP_G8_MAX_K
 #define TCLIP_G8_MAX_K 0              // 8 lanes per row: measured slower than 16 at 1000 tasks (too few wavefronts: K = 10 / 37 / 47:
                                       // 81 / 166 / 211 ms against 71 / 151 / 174), 2 % faster at 3000 tasks of K = 100; not compiled by default
@@ -2087,7 +2102,7 @@ static int enqueue_batches(const tclip_problem& p, const float* x_q, const float
             const int g8 = (TK + 7) / 8 > 65535 * 8 ? 65535 * 8 : (TK + 7) / 8;
             dispatch_E<LaunchRowConsts>(K, g8 > 4096 ? 4096 : g8, st, (const float*)alpha, (const int32_t*)live_rows,
                                         (const int32_t*)(counts + 1), K, rowc);
-            dispatch_E<LaunchLogits>(K, TK > 16384 ? 16384 : TK, st, (const float*)alpha, (const float*)logz, (const float*)rowc,
+            dispatch_E<LaunchLogits>(K, TK > TCLIP_LOGITS_GRID ? TCLIP_LOGITS_GRID : TK, st, (const float*)alpha, (const float*)logz, (const float*)rowc,
                                      (const int32_t*)live_rows, (const int32_t*)(counts + 1), Q, K, logit0, (const int32_t*)nullptr);
         }
         hipLaunchKernelGGL(k_softmax, dim3((T * Q * 16 + 255) / 256), dim3(256), 0, st, (const float*)logit0, (const float*)v,
