@@ -155,8 +155,21 @@ __device__ __forceinline__ f2 pk_lgamma_sleef_1_23(f2 x) {
 }
 
 // torch.sqrt, see sqrt_torch_inrange_f32
+// both table look-ups of a pair issued together (one memory latency per pair instead of two in a row)
+__device__ __forceinline__ f2 pk_rsqrt14(f2 x) {
+    const uint32_t b0 = f32_bits(x.x), b1 = f32_bits(x.y);
+    const int ue0 = (int)(b0 >> 23) - 127, ue1 = (int)(b1 >> 23) - 127;
+    const int par0 = ue0 & 1, par1 = ue1 & 1;
+    const uint32_t mant0 = b0 & 0x7fffffu, mant1 = b1 & 0x7fffffu;
+    const uint32_t t0 = kRsqrt14Tab[((uint32_t)par0 << 15) | (mant0 >> 8)];
+    const uint32_t t1 = kRsqrt14Tab[((uint32_t)par1 << 15) | (mant1 >> 8)];
+    const uint32_t y0 = (mant0 == 0u && par0 == 0) ? 0x3f800000u : (0x3f000000u | (t0 << 7));
+    const uint32_t y1 = (mant1 == 0u && par1 == 0) ? 0x3f800000u : (0x3f000000u | (t1 << 7));
+    return f2{bits_f32(y0 - ((uint32_t)((ue0 - par0) >> 1) << 23)), bits_f32(y1 - ((uint32_t)((ue1 - par1) >> 1) << 23))};
+}
+
 __device__ __forceinline__ f2 pk_sqrt_torch_inrange(f2 x) {
-    const f2 y{rsqrt14_f32(x.x), rsqrt14_f32(x.y)};
+    const f2 y = pk_rsqrt14(x);
     const f2 s = x * y;
     return pk_fma(pk_fma(-s, s, x), pk(0.5f) * y, s);
 }
