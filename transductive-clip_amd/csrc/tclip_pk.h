@@ -38,6 +38,25 @@ __device__ __forceinline__ f2 pk_div_rn(f2 a, f2 b) {
     return pk_fma(rem, r, q);
 }
 
+// logf_glibc_tab of two arguments that are not 1.0f (here: >= 10, the recurrence has run), without its x == 1 branch
+// and with both table entries fetched before either is used
+__device__ __forceinline__ f2 pk_logf_glibc_ne1(f2 x, const LogTabEntry* tab) {
+    const uint32_t ix0 = f32_bits(x.x), ix1 = f32_bits(x.y);
+    const uint32_t tmp0 = ix0 - 0x3f330000u, tmp1 = ix1 - 0x3f330000u;
+    const LogTabEntry e0 = tab[(tmp0 >> 19) & 15], e1 = tab[(tmp1 >> 19) & 15];
+    const double z0 = (double)bits_f32(ix0 - (tmp0 & 0xff800000u)), z1 = (double)bits_f32(ix1 - (tmp1 & 0xff800000u));
+    const double r0 = __builtin_fma(z0, e0.invc, -1.0), r1 = __builtin_fma(z1, e1.invc, -1.0);
+    const double y00 = e0.logc + (double)((int32_t)tmp0 >> 23) * kLn2, y01 = e1.logc + (double)((int32_t)tmp1 >> 23) * kLn2;
+    const double q0 = r0 * r0, q1 = r1 * r1;
+    double y0 = __builtin_fma(0x1.5575b0be00b6ap-2, r0, -0x1.ffffef20a4123p-2);
+    double y1 = __builtin_fma(0x1.5575b0be00b6ap-2, r1, -0x1.ffffef20a4123p-2);
+    y0 = __builtin_fma(-0x1.00ea348b88334p-2, q0, y0);
+    y1 = __builtin_fma(-0x1.00ea348b88334p-2, q1, y1);
+    y0 = __builtin_fma(y0, q0, y00 + r0);
+    y1 = __builtin_fma(y1, q1, y01 + r1);
+    return f2{(float)y0, (float)y1};
+}
+
 // digamma(a+1), see digamma_xp1.  The step mask is a float: acc - m*RN(1/x) and x + m round
 // once, exactly as the scalar's conditional updates (m*r is exact for m in {0,1}).
 __device__ __forceinline__ f2 pk_digamma_xp1(f2 a, const LogTabEntry* tab) {
@@ -58,7 +77,7 @@ __device__ __forceinline__ f2 pk_digamma_xp1(f2 a, const LogTabEntry* tab) {
     p = pk_fma(p, z, pk(-8.33333333333333333333E-3f));
     p = pk_fma(p, z, pk(8.33333333333333333333E-2f));
     const f2 y = z * p;
-    const f2 lg{logf_glibc_tab(x.x, tab), logf_glibc_tab(x.y, tab)};
+    const f2 lg = pk_logf_glibc_ne1(x, tab);
     const f2 series = ((acc + lg) - pk(0.5f) * pk_rcp_rn(x)) - y;
     return pk_sel(x == pk(10.0f), acc + pk(2.25175258906672110764f), series);
 }
