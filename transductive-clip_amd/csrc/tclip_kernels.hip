@@ -490,18 +490,11 @@ __device__ __forceinline__ void mm_apply_updates(float (&beta)[E], const RowY<E,
                                                  const LogTabEntry* tab, const float* queue, int base, bool measure,
                                                  double& num, double& den) {
     const int n_full = full_registers<E, G>(K);    // registers below it hold only elements of the row (wave-uniform)
-#pragma unroll
-    for (int p = 0; p < (TCLIP_MM_PACKED ? E / 2 : 0); p++) {
+    // finishes pair p (the square root's table entries were requested one pair ago), stores and measures it
+    auto finish = [&](int p, const PkUpdateStage& st) {
         const int e = 2 * p;
         const f2 a{beta[e], beta[e + 1]};
-        const bool big0 = a.x + 1.0f >= 2.3f, big1 = a.y + 1.0f >= 2.3f;
-        const unsigned long long m0 = __builtin_amdgcn_ballot_w64(big0);
-        const float lg0 = big0 ? queue[base + lanes_below(m0)] : 0.0f;
-        base += __popcll(m0);
-        const unsigned long long m1 = __builtin_amdgcn_ballot_w64(big1);
-        const float lg1 = big1 ? queue[base + lanes_below(m1)] : 0.0f;
-        base += __popcll(m1);
-        const f2 nb = pk_mm_update(a, f2{yv.get(e), yv.get(e + 1)}, pk(psi_s), f2{lg0, lg1}, tab);
+        const f2 nb = pk_mm_update_stage2(st);
         const bool full = e + 1 < n_full;
         const bool ok0 = full || elem_of<E, G>(e, lane) < K, ok1 = full || elem_of<E, G>(e + 1, lane) < K;
         if (measure) {
@@ -516,7 +509,24 @@ __device__ __forceinline__ void mm_apply_updates(float (&beta)[E], const RowY<E,
             beta[e] = ok0 ? nb.x : 0.0f;
             beta[e + 1] = ok1 ? nb.y : 0.0f;
         }
+    };
+    PkUpdateStage pending;
+#pragma unroll
+    for (int p = 0; p < (TCLIP_MM_PACKED ? E / 2 : 0); p++) {
+        const int e = 2 * p;
+        const f2 a{beta[e], beta[e + 1]};
+        const bool big0 = a.x + 1.0f >= 2.3f, big1 = a.y + 1.0f >= 2.3f;
+        const unsigned long long m0 = __builtin_amdgcn_ballot_w64(big0);
+        const float lg0 = big0 ? queue[base + lanes_below(m0)] : 0.0f;
+        base += __popcll(m0);
+        const unsigned long long m1 = __builtin_amdgcn_ballot_w64(big1);
+        const float lg1 = big1 ? queue[base + lanes_below(m1)] : 0.0f;
+        base += __popcll(m1);
+        const PkUpdateStage st = pk_mm_update_stage1(a, f2{yv.get(e), yv.get(e + 1)}, pk(psi_s), f2{lg0, lg1}, tab);
+        if (p > 0) finish(p - 1, pending);         // while this pair's table look-ups are in flight
+        pending = st;
     }
+    if (TCLIP_MM_PACKED && E / 2 > 0) finish(E / 2 - 1, pending);
 #pragma unroll
     for (int e = (TCLIP_MM_PACKED ? E / 2 * 2 : 0); e < E; e++) {
         const float a = beta[e];

@@ -215,4 +215,42 @@ __device__ __forceinline__ f2 pk_mm_update(f2 a, f2 y, f2 psi_s, f2 lg_big, cons
     return pk_mm_update_algebra(a, y, psi_s, psi1, pk_sel(big, lg_big, lg_small));
 }
 
+// The same update in two stages, so that a caller can put other work (the next pair's digamma) between the
+// table look-ups of torch.sqrt's VRSQRT14 emulation and their first use: stage 1 ends by issuing the two loads.
+struct PkUpdateStage {
+    f2 b, curv, delta;
+    uint32_t t0, t1;            // table entries of delta.x, delta.y (loaded, not yet used)
+};
+__device__ __forceinline__ PkUpdateStage pk_mm_update_stage1(f2 a, f2 y, f2 psi_s, f2 lg_big, const LogTabEntry* tab) {
+    const f2 x1 = a + pk(1.0f);
+    const i2 big = x1 >= pk(2.3f);
+    const f2 lg_small = pk_lgamma_sleef_1_23(pk_sel(big, pk(2.0f), x1));
+    const f2 psi1 = pk_digamma_xp1(a, tab);
+    const f2 lg1 = pk_sel(big, lg_big, lg_small);
+    const f2 t = (pk(0.0f) - lg1) + psi1 * a;
+    const f2 bigv = __builtin_elementwise_abs(pk_div_rn(pk(2.0f) * t, a * a));
+    PkUpdateStage st;
+    st.curv = pk_sel(a > pk(1e-11f), bigv, pk(1.6449340668482264f));
+    f2 b = (psi1 - psi_s) - st.curv * a;
+    st.b = b - y;
+    st.delta = st.b * st.b + pk(4.0f) * st.curv;
+    const uint32_t b0 = f32_bits(st.delta.x), b1 = f32_bits(st.delta.y);
+    st.t0 = kRsqrt14Tab[((((b0 >> 23) - 127u) & 1u) << 15) | ((b0 & 0x7fffffu) >> 8)];
+    st.t1 = kRsqrt14Tab[((((b1 >> 23) - 127u) & 1u) << 15) | ((b1 & 0x7fffffu) >> 8)];
+    return st;
+}
+__device__ __forceinline__ f2 pk_mm_update_stage2(const PkUpdateStage& st) {
+    const uint32_t b0 = f32_bits(st.delta.x), b1 = f32_bits(st.delta.y);
+    const int ue0 = (int)(b0 >> 23) - 127, ue1 = (int)(b1 >> 23) - 127;
+    const int par0 = ue0 & 1, par1 = ue1 & 1;
+    const uint32_t mant0 = b0 & 0x7fffffu, mant1 = b1 & 0x7fffffu;
+    const uint32_t y0 = (mant0 == 0u && par0 == 0) ? 0x3f800000u : (0x3f000000u | (st.t0 << 7));
+    const uint32_t y1 = (mant1 == 0u && par1 == 0) ? 0x3f800000u : (0x3f000000u | (st.t1 << 7));
+    const f2 yr{bits_f32(y0 - ((uint32_t)((ue0 - par0) >> 1) << 23)), bits_f32(y1 - ((uint32_t)((ue1 - par1) >> 1) << 23))};
+    const f2 s = st.delta * yr;
+    const f2 root = pk_fma(pk_fma(-s, s, st.delta), pk(0.5f) * yr, s);
+    const f2 nume = -st.b + root, deno = pk(2.0f) * st.curv;
+    return pk_sel(deno == pk(0.0f), nume * pk(__builtin_inff()), pk_div_rn(nume, deno));
+}
+
 }  // namespace tclip
