@@ -91,6 +91,12 @@ SMALL = {
     "zs_hkm_K37_N6": ("zs_hkm", 37, 6, 20, 0, 2021, True),
     "zs_hkm_K100_N4": ("zs_hkm", 100, 4, 20, 0, 2022, True),
     "zs_hkm_K397_N2": ("zs_hkm", 397, 2, 20, 0, 2023, True),
+    # the class counts of the reference's other datasets (dtd 47, flowers102 102, stanfordcars 196): rows of these lengths
+    # run on 16 lanes with 3, 7 and 13 registers per lane
+    "zs_soft_K47_N3": ("zs_soft", 47, 3, 20, 0, 2070, True),
+    "zs_soft_K102_N2": ("zs_soft", 102, 2, 20, 0, 2071, True),
+    "zs_hard_K196_N2": ("zs_hard", 196, 2, 10, 0, 2072, True),
+    "fs_hard_K47_N3_s2": ("fs_hard", 47, 3, 10, 2, 2073, True),
     # found by tests/golden/find_borderline.py: a stop test of these runs lands within 1e-4 (relative) of the 1e-11 threshold
     "zs_soft_K8_N2_borderline": ("zs_soft", 8, 2, 20, 0, 6087, True),
     "zs_soft_K5_N2_borderline": ("zs_soft", 5, 2, 20, 0, 5574, True),
