@@ -176,6 +176,9 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-secondary", action="store_true")
     ap.add_argument("--workload", choices=["k1000", "k100"], default="k1000", help="headline workload (k100: round-1 shape)")
+    ap.add_argument("--scaling", choices=["weak", "strong"], default="weak",
+                    help="weak (default): 10 batches per GPU, N = 8 is configs[3]; strong: the whole configs[3] job (80 batches of 125 "
+                         "K = 1000 tasks) on N GPUs - 90 s per step on one GPU")
     ap.add_argument("--backend", default="nccl", help="process-group backend (nccl = RCCL; gloo only to test the N>1 path on one GPU)")
     ap.add_argument("--single-device", action="store_true", help="testing: every rank uses cuda:0")
     args = ap.parse_args()
@@ -213,7 +216,7 @@ def main():
         """Feature table in HBM + the index stream of every batch (same on every rank)."""
         K = w["K"]
         feats, labels = synth.make_feature_table(K, w["rows_per_class"], seed=2020)
-        n_tasks = w["tasks_per_batch"] * w["batches_per_gpu"] * n_ranks
+        n_tasks = w["tasks_per_batch"] * w["batches_per_gpu"] * (8 if args.scaling == "strong" else n_ranks)
         cfg = CfgNode(iter=ITERS, iter_mm=ITER_MM, num_classes_test=K, n_class=K, n_query=N_QUERY, k_eff=5, T=30,
                       use_softmax_feature=True, graph_matching=True, shots=0, number_tasks=n_tasks,
                       batch_size=w["tasks_per_batch"], name_method="EM_DIRICHLET", used_test_set="test")
@@ -247,7 +250,8 @@ def main():
     mm_iters = ev.last_method.mm_iters                  # (local batches, iters)
     line = None
     if rank == 0:
-        tasks = world * head["tasks_per_batch"] * head["batches_per_gpu"] * steps
+        job = (8 if args.scaling == "strong" else world) * head["tasks_per_batch"] * head["batches_per_gpu"]
+        tasks = job * steps
         K = head["K"]
         roof = roofline_of(prof, steps, K, head["name"])
         roof["element_updates_reference_semantics_per_step"] = float(K) ** 2 * head["tasks_per_batch"] * float(mm_iters.sum())
@@ -255,9 +259,9 @@ def main():
             "metric": "transductive tasks/sec (75-query EM-Dirichlet)",
             "value": tasks / elapsed, "unit": "tasks/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": 1e3 * elapsed / steps, "higher_is_better": True,
-            "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "scaling": args.scaling, "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": head["text"], "n_class": K, "n_query": N_QUERY, "tasks_per_batch": head["tasks_per_batch"],
-                       "batches_per_gpu": head["batches_per_gpu"], "tasks_total": world * head["tasks_per_batch"] * head["batches_per_gpu"],
+                       "batches_per_gpu": head["batches_per_gpu"] * (8 // world if args.scaling == "strong" else 1), "tasks_total": job,
                        "parallelism": f"batch-sharded x{world}, one all_gather of per-task accuracies",
                        "path": "Evaluator_zero_shot.evaluate_tasks (device gather from a 50-rows-per-class synthetic table, "
                                "engine, accuracy tail, gather)",

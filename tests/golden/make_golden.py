@@ -144,6 +144,8 @@ LARGE = {
     # few-shot at sun397 / imagenet class counts (the reference's (N,S,K,K) temporary is 0.5 GB / 4 GB here)
     "fs_soft_K397_N1_s2": ("fs_soft", 397, 1, 20, 2, 2062, False),
     "fs_soft_K1000_N1_s1": ("fs_soft", 1000, 1, 20, 1, 2063, False),
+    # three tasks coupled by the MM stop test at K = 1000: the reference's fp32 norm runs over 3e6 elements per checkpoint
+    "zs_soft_K1000_N3": ("zs_soft", 1000, 3, 20, 0, 2064, False),
 }
 
 
