@@ -81,3 +81,39 @@ def test_tuned_parameter_comes_from_the_validation_sweep(tmp_path):
     a.name_method, a.temp = "BDCSPN", 30.0
     (d / "BDCSPN_softmax_s4.txt").write_text("val_param\tacc\n\t\n15.0\t60.0\t\n")
     assert ev.set_method_opt_param() == 15.0 and a.temp == 15.0
+
+
+def test_validation_sweep_file_round_trip(tmp_path):
+    """eval_few_shot.py:282-302 writes one header line and a `param<TAB>acc<TAB>` row per validation run (whatever
+    save_results says); the reader (:168-176) skips TWO lines, so the first row of a sweep never competes - kept."""
+    import torch
+    from src.eval_few_shot import Evaluator_few_shot
+    a = CfgNode(dataset="dtd", name_method="PADDLE", use_softmax_feature=True, shots=2, lambd=0.0, n_query=75, k_eff=5,
+                number_tasks=100, results_root=str(tmp_path), tunable=True, used_test_set="val", save_results=False)
+    ev = Evaluator_few_shot(torch.device("cpu"), a, None)
+    for lambd, acc in ((0.0, 0.9), (5.0, 0.71234), (10.0, 0.8), (20.0, 0.8), (50.0, 0.3)):
+        a.lambd = lambd
+        p = ev.report_results(acc, 0.01)
+    assert p.endswith("results_few_shot/val/dtd/PADDLE_softmax_s2.txt")
+    assert open(p).read() == "val_param\tacc\n0.0\t90.0\t\n5.0\t71.23\t\n10.0\t80.0\t\n20.0\t80.0\t\n50.0\t30.0\t\n"
+    a.used_test_set = "test"
+    assert ev.set_method_opt_param() == 20.0 and a.lambd == 20.0      # 0.0 scored best but sits on a skipped line
+    assert ev.report_results(0.5, 0.01) is None                      # test mode, save_results off: log only
+    a.save_results = True
+    assert ev.report_results(0.5, 0.01).endswith("results_few_shot/test/dtd/PADDLE_softmax_s2.txt")
+    a.used_test_set, a.name_method = "val", "EM_DIRICHLET"           # not tunable: the reference fails on self.val_param
+    with pytest.raises(AttributeError):
+        ev.report_results(0.5, 0.01)
+
+
+def test_full_evaluation_needs_the_saved_feature_files(tmp_path):
+    import torch
+    from src.eval_few_shot import Evaluator_few_shot
+    from src.eval_zero_shot import Evaluator_zero_shot
+    a = CfgNode(dataset="dtd", name_method="EM_DIRICHLET", use_softmax_feature=True, shots=0, backbone="RN50", T=30,
+                used_test_set="test", results_root=str(tmp_path))
+    with pytest.raises(FileNotFoundError, match="data/dtd/saved_features/test_softmax_RN50_T30.plk"):
+        Evaluator_zero_shot(torch.device("cpu"), a, None).run_full_evaluation(None, None)
+    a.shots, a.use_softmax_feature = 4, False
+    with pytest.raises(FileNotFoundError, match="data/dtd/saved_features/train_visual_RN50.plk"):
+        Evaluator_few_shot(torch.device("cpu"), a, None).run_full_evaluation(None, None)

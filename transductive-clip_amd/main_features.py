@@ -14,7 +14,7 @@ DIR/datasets_config/config_<dataset>.yaml and DIR/methods_config/<method>.yaml, 
 the command line wins over all three files (values are literal-eval'ed, an override must keep the type of
 the value it replaces).  Without a config directory the built-in copies of the reference's defaults below are
 used the same way.  Test-split runs of a tunable few-shot method (PADDLE, BDCSPN) need the validation sweep
-file under <results-root>/results_few_shot/val/, exactly as the reference does.
+file under <results-root>/results_few_shot/val/, exactly as the reference does; runs with `used_test_set val` append to it.
 Under `python -m torch.distributed.run --nproc-per-node N` batches are sharded over N GPUs.
 """
 import argparse

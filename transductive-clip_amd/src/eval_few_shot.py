@@ -14,7 +14,7 @@ from src.methods.few_shot.bdcspn import BDCSPN
 from src.sampler_few_shot import CategoriesSampler_few_shot, SamplerQuery_few_shot, SamplerSupport_few_shot
 from src.task_generator_few_shot import relabel
 from src.utils import Logger, compute_confidence_interval
-from tclip_amd import engine, sharding
+from tclip_amd import engine, features, reporting, sharding
 
 def _as_tensor(x):
     return x if torch.is_tensor(x) else torch.as_tensor(np.asarray(x))
@@ -42,8 +42,33 @@ class Evaluator_few_shot:
         self.logger = Logger(__name__, self.log_file)
 
     def run_full_evaluation(self, model, preprocess):
-        raise NotImplementedError("CLIP feature extraction is outside this package: extract the "
-                                  "softmax features with the reference and call evaluate_tasks()")
+        """eval_few_shot.py:42-74 from saved feature files (see Evaluator_zero_shot.run_full_evaluation): the
+        support table is the train split, the query table the `used_test_set` split."""
+        dic_s, dic_q = self.extract_and_load_features(model, None, None)
+        mean_accuracies, mean_times = self.evaluate_tasks(
+            model, dic_s['concat_features'].to('cpu'), dic_s['concat_labels'].long().to('cpu'),
+            dic_q['concat_features'].to('cpu'), dic_q['concat_labels'].long().to('cpu'))
+        if mean_accuracies is not None:
+            self.report_results(mean_accuracies, mean_times)
+        return mean_accuracies, mean_times
+
+    def extract_and_load_features(self, model, dataset, data_loaders):
+        """eval_few_shot.py:91-128, loading only."""
+        root = getattr(self.args, 'results_root', '.')
+        out = []
+        for split in ('train', self.args.used_test_set):
+            path = reporting.saved_feature_path(self.args, split, root)
+            if not os.path.exists(path):
+                raise FileNotFoundError(f"{path} not found: this package runs the reference's evaluation from saved "
+                                        "feature files; extract them with the reference (CLIP is out of scope here)")
+            feats, labels = features.load_features(path)
+            out.append({'concat_features': feats, 'concat_labels': labels})
+        return out[0], out[1]
+
+    def report_results(self, mean_accuracies, mean_times):
+        """eval_few_shot.py:272-338 (validation sweep row, or the test-mode row)."""
+        return reporting.report_results(self.args, mean_accuracies, mean_times, self.logger,
+                                        root=getattr(self.args, 'results_root', '.'))
 
     def get_method_builder(self, model, device, args, log_file):
         try:

@@ -5,8 +5,10 @@ table lives on the GPU, rows are gathered there, and every batch of this rank ru
 call with n_batches > 1 (each batch keeps its own MM stop test).  With torch.distributed
 initialised, batches are dealt round-robin to the ranks and gathered once onto rank 0.
 
-Feature extraction, dataset handling and result files of the reference's Evaluator are out of
-scope (they need CLIP weights and images); run_full_evaluation says so."""
+Feature extraction and dataset handling of the reference's Evaluator are out of scope (they need CLIP
+weights and images): run_full_evaluation starts from the saved feature files the reference writes."""
+import os
+
 import numpy as np
 import torch
 
@@ -20,7 +22,7 @@ from src.methods.zero_shot.kl_kmeans import KL_KMEANS
 from src.methods.zero_shot.soft_kmeans import SOFT_KMEANS
 from src.sampler_zero_shot import CategoriesSampler_zero_shot, SamplerQuery_zero_shot
 from src.utils import Logger, compute_confidence_interval
-from tclip_amd import engine, sharding
+from tclip_amd import engine, features, reporting, sharding
 
 def _as_tensor(x):
     return x if torch.is_tensor(x) else torch.as_tensor(np.asarray(x))
@@ -39,8 +41,32 @@ class Evaluator_zero_shot:
         self.logger = Logger(__name__, self.log_file)
 
     def run_full_evaluation(self, model, preprocess):
-        raise NotImplementedError("CLIP feature extraction is outside this package: extract the "
-                                  "softmax features with the reference and call evaluate_tasks()")
+        """eval_zero_shot.py:44-72 for the case the reference itself short-cuts: when the feature file of the
+        split is already saved the reference skips CLIP (utils.py:266-271 "Features already saved ... skipping")
+        and goes from the pickle to evaluate_tasks and report_results; `model`/`preprocess` are then unused and
+        may be None.  Extracting features needs CLIP and the image datasets and is not part of this package."""
+        dic = self.extract_and_load_features(model, None, None)
+        all_features_query = dic['concat_features'].to('cpu')
+        all_labels_query = dic['concat_labels'].long().to('cpu')
+        mean_accuracies, mean_times = self.evaluate_tasks(model, all_features_query, all_labels_query)
+        if mean_accuracies is not None:            # rank 0 (every rank without torch.distributed)
+            self.report_results(mean_accuracies, mean_times)
+        return mean_accuracies, mean_times
+
+    def extract_and_load_features(self, model, dataset, data_loaders):
+        """Loads data/<dataset>/saved_features/<split>_{softmax_<backbone>_T<T>,visual_<backbone>}.plk
+        (eval_zero_shot.py:89-111) under args.results_root (default: the working directory, as in the reference)."""
+        path = reporting.saved_feature_path(self.args, self.args.used_test_set, getattr(self.args, 'results_root', '.'))
+        if not os.path.exists(path):
+            raise FileNotFoundError(f"{path} not found: this package runs the reference's evaluation from saved "
+                                    "feature files; extract them with the reference (CLIP is out of scope here)")
+        feats, labels = features.load_features(path)
+        return {'concat_features': feats, 'concat_labels': labels}
+
+    def report_results(self, mean_accuracies, mean_times):
+        """eval_zero_shot.py:189-232."""
+        return reporting.report_results(self.args, mean_accuracies, mean_times, self.logger,
+                                        root=getattr(self.args, 'results_root', '.'))
 
     def get_method_builder(self, model, device, args, log_file):
         try:
