@@ -174,6 +174,33 @@ int tclip_paddle_run(const tclip_problem* p, const float* x_q, const float* x_s,
                      float* u, float* v, float* w, int32_t* preds, void* workspace, size_t workspace_bytes,
                      void* stream);
 
+/* ALPHA_TIM on probability features (reference: src/methods/few_shot/tim.py:192-322; feature dimension =
+ * n_class).  Weights start as the class means of the support set; each of `iters` iterations takes one
+ * torch.optim.Adam step (betas 0.9/0.999, eps 1e-8) of size lr on
+ *   loss_weights[0] * CE(support) - (loss_weights[1] * H(mean_q p_q) - loss_weights[2] * mean_q H(p_q)),
+ * p = softmax_k(temp * (x.w_k - |w_k|^2/2 - |x|^2/2)), every entropy either Shannon or the alpha-entropy of
+ * order alpha_value (tim.py:276-305), with the gradient in closed form instead of autograd.  The reference's
+ * matmuls and backward pass have no fixed operation order, so this entry is pinned to the reference within a
+ * float tolerance (tests/test_alpha_tim.py), not bit for bit.  Uses n_batches, tasks_per_batch, n_query,
+ * n_class, n_support, iters (>= 1).
+ *   x_q device [T,Q,K] f32;  x_s device [T,S,K] f32;  y_s device [T,S] i64;
+ *   weights device [T,K,K] out (after the last step);  logits_q device [T,Q,K] out and preds device [T,Q] i32
+ *   out: the query logits of the LAST iteration's forward pass and their argmax, which is what the reference
+ *   scores (tim.py:321);  criterions device [n_batches, iters] out: mean_{task,class} ||w_old - w|| per step. */
+#define TCLIP_TIM_SHANNON 0
+#define TCLIP_TIM_ALPHA 1
+typedef struct tclip_tim_params {
+    double lr;               /* lr_alpha_tim */
+    float temp;              /* args.temp */
+    float alpha_value;       /* order of the alpha-entropies */
+    float loss_weights[3];   /* [cross-entropy, marginal entropy, conditional entropy] */
+    int32_t entropies[3];    /* TCLIP_TIM_SHANNON / TCLIP_TIM_ALPHA for the same three terms */
+} tclip_tim_params;
+size_t tclip_alpha_tim_workspace_bytes(const tclip_problem* p);
+int tclip_alpha_tim_run(const tclip_problem* p, const tclip_tim_params* prm, const float* x_q, const float* x_s,
+                        const int64_t* y_s, float* weights, float* logits_q, int32_t* preds, float* criterions,
+                        void* workspace, size_t workspace_bytes, void* stream);
+
 /* Inductive zero-shot CLIP on probability features (reference: src/methods/zero_shot/inductive_clip.py:45-49,
  * 112-126): the prediction is the arg-max of each query's probability vector, no adaptation.
  *   x device [n_rows, n_class] f32;  labels device [n_rows] i32 out (first maximum, as torch.argmax). */

@@ -388,3 +388,56 @@ def run_kl_kmeans(x_q, *, n_class, iters):
         u_old = u.clone()
     return {"u": u, "w": w, "criterions": torch.stack(criterions), "labels": torch.stack(labels_all),
             "seconds": time.time() - t0}
+
+
+def run_alpha_tim(x_q, x_s, y_s, *, n_class, iters, temp, lr, alpha_value, loss_weights=(1.0, 1.0, 1.0),
+                  entropies=("Shannon", "Alpha", "Alpha")):
+    """ALPHA_TIM, the reference's torch op sequence with autograd and torch.optim.Adam
+    (src/methods/few_shot/tim.py:192-322): weights = support class means, then `iters` Adam steps on
+    lw0 * ce - (lw1 * q_ent - lw2 * q_cond_ent) with logits temp * (x w^T - |w|^2/2 - |x|^2/2).
+    Returns dict(weights, logits_q (last iteration's forward pass), criterions (iters,), argmax (N,Q), seconds)."""
+    support, query = x_s.clone().float(), x_q.clone().float()
+    n_task = query.shape[0]
+    y_s = y_s.long().view(n_task, -1)
+    t0 = time.time()
+    ys_hot = one_hot_rows(y_s, n_class)
+    counts = ys_hot.sum(1).view(n_task, -1, 1)
+    weights = (ys_hot.transpose(1, 2).matmul(support) / counts).requires_grad_()
+
+    def get_logits(samples):
+        return temp * (samples.matmul(weights.transpose(1, 2)) - 1 / 2 * (weights ** 2).sum(2).view(n_task, 1, -1)
+                       - 1 / 2 * (samples ** 2).sum(2).view(n_task, -1, 1))
+
+    optimizer = torch.optim.Adam([weights], lr=lr)
+    lw, a, criterions, logits_q = list(loss_weights), alpha_value, [], None
+    for _ in range(iters):
+        weights_old = weights.detach().clone()
+        logits_s, logits_q = get_logits(support), get_logits(query)
+        q_probs = logits_q.softmax(2)
+        if entropies[0] == "Shannon":
+            ce = -(ys_hot * torch.log(logits_s.softmax(2) + 1e-12)).sum(2).mean(1).sum(0)
+        elif entropies[0] == "Alpha":
+            ce = torch.pow(ys_hot, a) * torch.pow(logits_s.softmax(2) + 1e-12, 1 - a)
+            ce = ((1 - ce.sum(2)) / (a - 1)).mean(1).sum(0)
+        else:
+            raise ValueError("Entropies must be in ['Shannon', 'Alpha']")
+        if entropies[1] == "Shannon":
+            q_ent = -(q_probs.mean(1) * torch.log(q_probs.mean(1))).sum(1).sum(0)
+        elif entropies[1] == "Alpha":
+            q_ent = ((1 - (torch.pow(q_probs.mean(1), a)).sum(1)) / (a - 1)).sum(0)
+        else:
+            raise ValueError("Entropies must be in ['Shannon', 'Alpha']")
+        if entropies[2] == "Shannon":
+            q_cond_ent = -(q_probs * torch.log(q_probs + 1e-12)).sum(2).mean(1).sum(0)
+        elif entropies[2] == "Alpha":
+            q_cond_ent = ((1 - (torch.pow(q_probs + 1e-12, a)).sum(2)) / (a - 1)).mean(1).sum(0)
+        else:
+            raise ValueError("Entropies must be in ['Shannon', 'Alpha']")
+        loss = lw[0] * ce - (lw[1] * q_ent - lw[2] * q_cond_ent)
+        optimizer.zero_grad()
+        loss.backward()
+        optimizer.step()
+        criterions.append((weights_old - weights.detach()).norm(dim=-1).mean())
+    logits_q = logits_q.detach()
+    return {"weights": weights.detach(), "logits_q": logits_q, "criterions": torch.stack(criterions),
+            "argmax": logits_q.argmax(2), "seconds": time.time() - t0}

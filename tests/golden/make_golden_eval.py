@@ -63,7 +63,7 @@ def main():
     seed = 2020
     only = set(sys.argv[1:])
     cases = [("zs", False, None), ("zs", True, None), ("fs", False, None),
-             ("zs", False, "HARD_KMEANS"), ("zs", False, "EM_GAUSSIAN"), ("zs", False, "EM_GAUSSIAN_COV"), ("zs", False, "SOFT_KMEANS"), ("zs", False, "KL_KMEANS"), ("zs", False, "CLIP"), ("fs", False, "PADDLE"), ("fs", False, "BDCSPN")]
+             ("zs", False, "HARD_KMEANS"), ("zs", False, "EM_GAUSSIAN"), ("zs", False, "EM_GAUSSIAN_COV"), ("zs", False, "SOFT_KMEANS"), ("zs", False, "KL_KMEANS"), ("zs", False, "CLIP"), ("fs", False, "PADDLE"), ("fs", False, "BDCSPN"), ("fs", False, "ALPHA_TIM")]
     for kind, hard, other in cases:
         K = 10
         method = other or ("HARD_EM_DIRICHLET" if hard else "EM_DIRICHLET")
@@ -73,6 +73,11 @@ def main():
                     n_query=75, k_eff=5, T=30, use_softmax_feature=True, graph_matching=True, shots=2, number_tasks=20,
                     batch_size=10, name_method=method, used_test_set="test", tunable=False, lambd=5.0,
                     method=method.lower(), dataset="synthetic", norm_type="L2N", temp=30.0, num_NN=1)
+        model = None
+        if other == "ALPHA_TIM":          # alpha_tim.yaml; the class toggles model.eval()/train(), so it needs an object
+            args.update(iter=1000, temp=15, loss_weights=[1.0, 1.0, 1.0], lr_alpha_tim=1e-4, entropies=["Shannon", "Alpha", "Alpha"],
+                        alpha_value=7.0)
+            model = types.SimpleNamespace(eval=lambda: None, train=lambda: None)
         feats, labels = synth.make_feature_table(K, 40, seed=seed)
         out = {"kind": kind, "hard": hard, "K": K, "seed": seed, "rows_per_class": 40, "method": method,
                "iters": args.iter, "lambd": args.lambd,
@@ -91,7 +96,7 @@ def main():
             oq = record_iter(ef.SamplerQuery_few_shot, q)
             os_ = record_iter(ef.SamplerSupport_few_shot, s)
             ev = ef.Evaluator_few_shot(device=torch.device("cpu"), args=args, log_file="/tmp/golden_eval.log")
-            acc, t = ev.evaluate_tasks(None, feats_s, labels_s, feats, labels)
+            acc, t = ev.evaluate_tasks(model, feats_s, labels_s, feats, labels)
             ef.SamplerQuery_few_shot.__iter__ = oq
             ef.SamplerSupport_few_shot.__iter__ = os_
             out["query_idx"] = torch.stack(q).numpy().reshape(2, 10, 75)

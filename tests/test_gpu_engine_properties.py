@@ -250,7 +250,7 @@ def test_bench_scale_call_equals_its_batches_run_alone():
 
 @pytest.mark.parametrize("name", ["eval_zs_soft_K10", "eval_zs_hard_K10", "eval_fs_soft_K10", "eval_zs_soft_kmeans_K10",
                                   "eval_zs_hard_kmeans_K10", "eval_zs_em_gaussian_K10", "eval_zs_em_gaussian_cov_K10", "eval_zs_kl_kmeans_K10", "eval_zs_clip_K10",
-                                  "eval_fs_paddle_K10", "eval_fs_bdcspn_K10"])
+                                  "eval_fs_paddle_K10", "eval_fs_bdcspn_K10", "eval_fs_alpha_tim_K10"])
 def test_task_batch_loop_matches_reference(name):
     """evaluate_tasks on the seeded synthetic table: the reference's mean accuracy (fixtures made
     by running the reference's Evaluator_*.evaluate_tasks), for every method behind the boundary."""
@@ -264,6 +264,10 @@ def test_task_batch_loop_matches_reference(name):
                 use_softmax_feature=True, graph_matching=True, shots=int(g["shots"]), number_tasks=int(g["number_tasks"]),
                 batch_size=int(g["batch_size"]), name_method=method, used_test_set="test",
                 lambd=float(g["lambd"]) if "lambd" in g.files else 0.0, norm_type="L2N", temp=30.0)     # bdcspn.yaml defaults
+    tol = 1e-7
+    if method == "ALPHA_TIM":      # alpha_tim.yaml; the one method pinned within a tolerance: at most one near-tied query may flip
+        a.update(temp=15, loss_weights=[1.0, 1.0, 1.0], lr_alpha_tim=1e-4, entropies=["Shannon", "Alpha", "Alpha"], alpha_value=7.0)
+        tol = 1.0 / (75 * int(g["number_tasks"])) + 1e-7
     feats, labels = synth.make_feature_table(K, int(g["rows_per_class"]), seed=int(g["seed"]))
     random.seed(int(g["seed"]))
     torch.manual_seed(int(g["seed"]))
@@ -275,7 +279,7 @@ def test_task_batch_loop_matches_reference(name):
         from src.eval_few_shot import Evaluator_few_shot
         fs, ls = synth.make_feature_table(K, int(g["support_rows_per_class"]), seed=int(g["seed"]) + 1)
         acc, t = Evaluator_few_shot(torch.device("cuda:0"), a, None).evaluate_tasks(None, fs, ls, feats, labels)
-    assert abs(float(acc) - float(g["mean_accuracy"])) < 1e-7
+    assert abs(float(acc) - float(g["mean_accuracy"])) < tol
     assert t > 0 or method == "CLIP"        # the reference logs a zero time for the inductive baseline
 
 

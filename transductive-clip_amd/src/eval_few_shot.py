@@ -11,6 +11,7 @@ from src.methods.few_shot.em_dirichlet import EM_DIRICHLET
 from src.methods.few_shot.hard_em_dirichlet import HARD_EM_DIRICHLET
 from src.methods.few_shot.paddle import PADDLE
 from src.methods.few_shot.bdcspn import BDCSPN
+from src.methods.few_shot.tim import ALPHA_TIM
 from src.sampler_few_shot import CategoriesSampler_few_shot, SamplerQuery_few_shot, SamplerSupport_few_shot
 from src.task_generator_few_shot import relabel
 from src.utils import Logger, compute_confidence_interval
@@ -31,7 +32,8 @@ def relabel_batch(x_s, x_q, y_s, y_q, use_softmax_feature):
     return torch.stack(xs2, 0), torch.stack(xq2, 0), torch.stack(ys2, 0), torch.stack(yq2, 0)
 
 
-_METHODS = {'EM_DIRICHLET': EM_DIRICHLET, 'HARD_EM_DIRICHLET': HARD_EM_DIRICHLET, 'PADDLE': PADDLE, 'BDCSPN': BDCSPN}
+_METHODS = {'EM_DIRICHLET': EM_DIRICHLET, 'HARD_EM_DIRICHLET': HARD_EM_DIRICHLET, 'PADDLE': PADDLE, 'BDCSPN': BDCSPN,
+            'ALPHA_TIM': ALPHA_TIM}
 
 
 class Evaluator_few_shot:

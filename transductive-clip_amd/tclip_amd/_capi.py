@@ -13,6 +13,11 @@ class Problem(ctypes.Structure):
         "n_batches", "tasks_per_batch", "n_query", "n_class", "n_support", "iters", "iter_mm", "lambd", "hard")]
 
 
+class TimParams(ctypes.Structure):
+    _fields_ = [("lr", ctypes.c_double), ("temp", ctypes.c_float), ("alpha_value", ctypes.c_float),
+                ("loss_weights", ctypes.c_float * 3), ("entropies", ctypes.c_int32 * 3)]
+
+
 _P = ctypes.c_void_p
 _SIGNATURES = {
     "tclip_abi_version": (ctypes.c_int, []),
@@ -30,6 +35,8 @@ _SIGNATURES = {
     "tclip_em_gaussian_cov_run": (ctypes.c_int, [ctypes.POINTER(Problem), _P, _P, _P, _P, _P, _P, _P, ctypes.c_size_t, _P]),
     "tclip_paddle_workspace_bytes": (ctypes.c_size_t, [ctypes.POINTER(Problem)]),
     "tclip_paddle_run": (ctypes.c_int, [ctypes.POINTER(Problem), _P, _P, _P, ctypes.c_float, _P, _P, _P, _P, _P, ctypes.c_size_t, _P]),
+    "tclip_alpha_tim_workspace_bytes": (ctypes.c_size_t, [ctypes.POINTER(Problem)]),
+    "tclip_alpha_tim_run": (ctypes.c_int, [ctypes.POINTER(Problem), ctypes.POINTER(TimParams)] + [_P] * 8 + [ctypes.c_size_t, _P]),
     "tclip_bdcspn_workspace_bytes": (ctypes.c_size_t, [ctypes.POINTER(Problem)]),
     "tclip_bdcspn_run": (ctypes.c_int, [ctypes.POINTER(Problem), _P, _P, _P, ctypes.c_float, ctypes.c_int32, _P, _P, _P, _P, ctypes.c_size_t, _P]),
     "tclip_hard_kmeans_workspace_bytes": (ctypes.c_size_t, [ctypes.POINTER(Problem)]),

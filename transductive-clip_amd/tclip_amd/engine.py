@@ -158,6 +158,31 @@ def run_paddle(x_q, x_s, y_s, *, iters, lambd):
     return u, v, w, preds
 
 
+ENTROPIES = {"Shannon": 0, "Alpha": 1}
+
+
+def run_alpha_tim(x_q, x_s, y_s, *, iters, temp, lr, alpha_value, loss_weights=(1.0, 1.0, 1.0),
+                  entropies=("Shannon", "Alpha", "Alpha"), n_batches=1):
+    """ALPHA_TIM: x_q (T,Q,K), x_s (T,S,K) f32 cuda, y_s (T,S) int64 cuda -> (weights (T,K,K), logits_q (T,Q,K) of the
+    last iteration's forward pass, preds (T,Q) i32 = their argmax, criterions (n_batches, iters)), cuda, not synchronised."""
+    for e in entropies:
+        if e not in ENTROPIES:
+            raise ValueError("Entropies must be in ['Shannon', 'Alpha']")        # tim.py:286, 295, 305
+    x_q = _query(x_q)
+    x_s, y_s = _support(x_q, x_s, y_s)
+    T, Q, K = x_q.shape
+    if T % n_batches:
+        raise ValueError("the number of tasks must be a multiple of n_batches")
+    prm = _capi.TimParams(float(lr), float(temp), float(alpha_value), (ctypes.c_float * 3)(*[float(w) for w in loss_weights]),
+                          (ctypes.c_int32 * 3)(*[ENTROPIES[e] for e in entropies]))
+    c = _Call(x_q.device, _capi.Problem(n_batches, T // n_batches, Q, K, x_s.shape[1], iters, 1, 0, 0),
+              "tclip_alpha_tim_workspace_bytes")
+    weights, logits_q, preds, crit = c.empty(T, K, K), c.empty(T, Q, K), c.empty(T, Q, dtype=torch.int32), c.empty(n_batches, iters)
+    c.launch("tclip_alpha_tim_run", lambda ws, n, st: (ctypes.byref(prm), _ptr(x_q), _ptr(x_s), _ptr(y_s), _ptr(weights),
+                                                       _ptr(logits_q), _ptr(preds), _ptr(crit), ws, n, st))
+    return weights, logits_q, preds, crit
+
+
 def argmax_rows(x):
     """x (..., K) f32 cuda -> int32 (...) indices of the first maximum of every row, cuda, not synchronised."""
     _require_cuda(x, "x")
