@@ -201,6 +201,22 @@ int tclip_alpha_tim_run(const tclip_problem* p, const tclip_tim_params* prm, con
                         const int64_t* y_s, float* weights, float* logits_q, int32_t* preds, float* criterions,
                         void* workspace, size_t workspace_bytes, void* stream);
 
+/* LAPLACIAN_SHOT on probability features (reference: src/methods/few_shot/laplacian_shot.py:66-249; feature
+ * dimension = n_class).  Rows L2-normalised (norm_type 1) or left as they are (0), prototypes = support class
+ * means, unary = squared distances query-prototype, a kNN graph over the queries of a task (the knn-1 nearest
+ * OTHER queries of each query, as `knnind[:, 1:]`), then `iters` bound updates Y <- softmax_k(-unary + lmd W Y)
+ * with the reference's energy and its freeze rule (:162-171).  Host numpy/scipy/sklearn code in the reference,
+ * one workgroup per task here; pinned to reference-made fixtures within a tolerance (tests/test_laplacian_shot.py).
+ * Uses n_batches * tasks_per_batch tasks, n_query (<= 1024), n_class, n_support, iters (>= 1).
+ *   x_q device [T,Q,K] f32;  x_s device [T,S,K] f32;  y_s device [T,S] i64;
+ *   unary device [T,Q,K] f32 out;  neighbours device [T,Q,knn-1] i32 out (nearest first);
+ *   preds_iter device [T,iters,Q] i32 out (the assignment after every update; the last one is the prediction);
+ *   energies device [T,iters] f64 out. */
+size_t tclip_laplacian_shot_workspace_bytes(const tclip_problem* p);
+int tclip_laplacian_shot_run(const tclip_problem* p, const float* x_q, const float* x_s, const int64_t* y_s, int32_t knn,
+                             double lmd, int32_t norm_type, float* unary, int32_t* neighbours, int32_t* preds_iter,
+                             double* energies, void* workspace, size_t workspace_bytes, void* stream);
+
 /* Inductive zero-shot CLIP on probability features (reference: src/methods/zero_shot/inductive_clip.py:45-49,
  * 112-126): the prediction is the arg-max of each query's probability vector, no adaptation.
  *   x device [n_rows, n_class] f32;  labels device [n_rows] i32 out (first maximum, as torch.argmax). */

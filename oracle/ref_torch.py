@@ -441,3 +441,58 @@ def run_alpha_tim(x_q, x_s, y_s, *, n_class, iters, temp, lr, alpha_value, loss_
     logits_q = logits_q.detach()
     return {"weights": weights.detach(), "logits_q": logits_q, "criterions": torch.stack(criterions),
             "argmax": logits_q.argmax(2), "seconds": time.time() - t0}
+
+
+def run_laplacian_shot(x_q, x_s, y_s, y_q, *, n_class, iters, knn, lmd, norm_type="L2N"):
+    """LAPLACIAN_SHOT, the reference's numpy / scipy.sparse / sklearn op sequence
+    (src/methods/few_shot/laplacian_shot.py:66-249) with `dtype=float` where the reference writes the removed alias
+    `np.float` (:100).  Returns dict(unary (N,Q,K) f32, neighbours (N,Q,knn-1) sorted, preds (N,Q), acc (N,iters),
+    ent_energy (N,iters) f64)."""
+    import numpy as np
+    from numpy import linalg as LA
+    from scipy import sparse
+    from sklearn.neighbors import NearestNeighbors
+    z_s, z_q = x_s.clone().float().cpu(), x_q.clone().float().cpu()
+    if norm_type == "L2N":
+        z_s = z_s / LA.norm(z_s, 2, 2)[:, :, None]
+        z_q = z_q / LA.norm(z_q, 2, 2)[:, :, None]
+    n_task = z_q.shape[0]
+    y_s = y_s.long().view(n_task, -1)
+    y_q = y_q.long().view(n_task, -1).numpy()
+    one_hot = one_hot_rows(y_s, n_class)
+    counts = one_hot.sum(1).view(n_task, -1, 1)
+    support = (one_hot.transpose(1, 2).matmul(z_s) / counts).numpy()
+    query = z_q.numpy()
+
+    def normalize(y_in):
+        y_in = y_in - np.max(y_in, axis=1)[:, np.newaxis]
+        y_out = np.exp(y_in)
+        return y_out / (np.sum(y_out, axis=1)[:, None])
+
+    out = {"unary": [], "neighbours": [], "preds": [], "acc": [], "ent_energy": []}
+    for i in range(n_task):
+        distance = LA.norm(support[i][:, None, :] - query[i], 2, axis=-1)
+        unary = distance.transpose() ** 2
+        n = query[i].shape[0]
+        _, knnind = NearestNeighbors(n_neighbors=knn).fit(query[i]).kneighbors(query[i])
+        row, col = np.repeat(range(n), knn - 1), knnind[:, 1:].flatten()
+        kernel = sparse.csc_matrix((np.ones(n * (knn - 1)), (row, col)), shape=(n, n), dtype=float)
+        old_e, y, energies, accs, pred = float("inf"), normalize(-unary), [], [], None
+        for it in range(iters):
+            y = normalize(-unary - (-lmd * kernel.dot(y)))
+            pairwise = kernel.dot(y)
+            e = (y * np.log(np.maximum(y, 1e-20)) + ((unary * y) + (-lmd * pairwise * y))).sum()
+            energies.append(e)
+            pred = np.argmax(y, axis=1)
+            accs.append(np.float32((y_q[i] == pred).astype(np.float32).mean()))
+            if it > 1 and abs(e - old_e) <= 1e-6 * abs(old_e):
+                energies += [e] * (iters - it - 1)
+                accs += [accs[-1]] * (iters - it - 1)
+                break
+            old_e = e
+        out["unary"].append(unary.astype(np.float32))
+        out["neighbours"].append(np.sort(knnind[:, 1:], axis=1))
+        out["preds"].append(pred)
+        out["acc"].append(accs)
+        out["ent_energy"].append(energies)
+    return {k: np.asarray(v) for k, v in out.items()}

@@ -30,6 +30,14 @@ sys.path[:] = [p for p in sys.path if "transductive-clip_amd" not in p]
 for _m in ("clip", "torchvision", "torchvision.transforms"):
     sys.modules.setdefault(_m, types.ModuleType(_m))
 REF = "/root/reference"
+try:                                    # laplacian_shot.py imports matplotlib only to select a backend
+    import matplotlib  # noqa: F401
+except ImportError:
+    _mpl = types.ModuleType("matplotlib")
+    _mpl.use = lambda *a, **k: None
+    sys.modules["matplotlib"] = _mpl
+if not hasattr(np, "float"):            # laplacian_shot.py:100 uses the alias numpy 1.24 removed; see make_golden_lshot.py
+    np.float = float
 
 
 class Args(dict):
@@ -63,7 +71,7 @@ def main():
     seed = 2020
     only = set(sys.argv[1:])
     cases = [("zs", False, None), ("zs", True, None), ("fs", False, None),
-             ("zs", False, "HARD_KMEANS"), ("zs", False, "EM_GAUSSIAN"), ("zs", False, "EM_GAUSSIAN_COV"), ("zs", False, "SOFT_KMEANS"), ("zs", False, "KL_KMEANS"), ("zs", False, "CLIP"), ("fs", False, "PADDLE"), ("fs", False, "BDCSPN"), ("fs", False, "ALPHA_TIM")]
+             ("zs", False, "HARD_KMEANS"), ("zs", False, "EM_GAUSSIAN"), ("zs", False, "EM_GAUSSIAN_COV"), ("zs", False, "SOFT_KMEANS"), ("zs", False, "KL_KMEANS"), ("zs", False, "CLIP"), ("fs", False, "PADDLE"), ("fs", False, "BDCSPN"), ("fs", False, "ALPHA_TIM"), ("fs", False, "LAPLACIAN_SHOT")]
     for kind, hard, other in cases:
         K = 10
         method = other or ("HARD_EM_DIRICHLET" if hard else "EM_DIRICHLET")
@@ -78,6 +86,8 @@ def main():
             args.update(iter=1000, temp=15, loss_weights=[1.0, 1.0, 1.0], lr_alpha_tim=1e-4, entropies=["Shannon", "Alpha", "Alpha"],
                         alpha_value=7.0)
             model = types.SimpleNamespace(eval=lambda: None, train=lambda: None)
+        if other == "LAPLACIAN_SHOT":     # laplacian_shot.yaml
+            args.update(iter=20, knn=3, lmd=0.7, norm_type="L2N", temp=30)
         feats, labels = synth.make_feature_table(K, 40, seed=seed)
         out = {"kind": kind, "hard": hard, "K": K, "seed": seed, "rows_per_class": 40, "method": method,
                "iters": args.iter, "lambd": args.lambd,

@@ -250,7 +250,7 @@ def test_bench_scale_call_equals_its_batches_run_alone():
 
 @pytest.mark.parametrize("name", ["eval_zs_soft_K10", "eval_zs_hard_K10", "eval_fs_soft_K10", "eval_zs_soft_kmeans_K10",
                                   "eval_zs_hard_kmeans_K10", "eval_zs_em_gaussian_K10", "eval_zs_em_gaussian_cov_K10", "eval_zs_kl_kmeans_K10", "eval_zs_clip_K10",
-                                  "eval_fs_paddle_K10", "eval_fs_bdcspn_K10", "eval_fs_alpha_tim_K10"])
+                                  "eval_fs_paddle_K10", "eval_fs_bdcspn_K10", "eval_fs_alpha_tim_K10", "eval_fs_laplacian_shot_K10"])
 def test_task_batch_loop_matches_reference(name):
     """evaluate_tasks on the seeded synthetic table: the reference's mean accuracy (fixtures made
     by running the reference's Evaluator_*.evaluate_tasks), for every method behind the boundary."""
@@ -268,6 +268,8 @@ def test_task_batch_loop_matches_reference(name):
     if method == "ALPHA_TIM":      # alpha_tim.yaml; the one method pinned within a tolerance: at most one near-tied query may flip
         a.update(temp=15, loss_weights=[1.0, 1.0, 1.0], lr_alpha_tim=1e-4, entropies=["Shannon", "Alpha", "Alpha"], alpha_value=7.0)
         tol = 1.0 / (75 * int(g["number_tasks"])) + 1e-7
+    if method == "LAPLACIAN_SHOT":   # laplacian_shot.yaml
+        a.update(knn=3, lmd=0.7, temp=30)
     feats, labels = synth.make_feature_table(K, int(g["rows_per_class"]), seed=int(g["seed"]))
     random.seed(int(g["seed"]))
     torch.manual_seed(int(g["seed"]))

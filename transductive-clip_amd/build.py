@@ -12,7 +12,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 OUT = os.path.join(HERE, "tclip_amd", "libtclip.so")
 SOURCES = ["tclip_kernels.hip", "tclip_host.cpp"]
-HEADERS = ["tclip_math.h", "tclip_device.h", "tclip_pk.h", "tclip_tim.inc", "tclip_selftest_inputs.h", "tclip_rsqrt14_table.h", "tclip_rcp14_log_table.h", os.path.join("..", "..", "include", "tclip.h")]
+HEADERS = ["tclip_math.h", "tclip_device.h", "tclip_pk.h", "tclip_tim.inc", "tclip_lshot.inc", "tclip_selftest_inputs.h", "tclip_rsqrt14_table.h", "tclip_rcp14_log_table.h", os.path.join("..", "..", "include", "tclip.h")]
 
 
 def hipcc():

@@ -2750,3 +2750,4 @@ int tclip_gather_rows(const float* table, int64_t n_rows, int32_t K, const int64
 }  // extern "C"
 
 #include "tclip_tim.inc"
+#include "tclip_lshot.inc"

@@ -48,6 +48,7 @@ METHOD_DEFAULTS = {
     "em_gaussian_cov": dict(name_method="EM_GAUSSIAN_COV", iter=20, graph_matching=True, tunable=False),
     "paddle": dict(name_method="PADDLE", iter=20, lambd=0.0, tunable=True),
     "bdcspn": dict(name_method="BDCSPN", num_NN=1, norm_type="L2N", temp=30.0, tunable=True),
+    "laplacian_shot": dict(name_method="LAPLACIAN_SHOT", knn=3, lmd=0.7, norm_type="L2N", iter=20, temp=30, tunable=True),
     "alpha_tim": dict(name_method="ALPHA_TIM", temp=15, loss_weights=[1.0, 1.0, 1.0], lr_alpha_tim=1e-4, iter=1000,
                       entropies=["Shannon", "Alpha", "Alpha"], alpha_value=7.0, acc_clustering=False, tunable=True),
 }

@@ -12,6 +12,7 @@ from src.methods.few_shot.hard_em_dirichlet import HARD_EM_DIRICHLET
 from src.methods.few_shot.paddle import PADDLE
 from src.methods.few_shot.bdcspn import BDCSPN
 from src.methods.few_shot.tim import ALPHA_TIM
+from src.methods.few_shot.laplacian_shot import LAPLACIAN_SHOT
 from src.sampler_few_shot import CategoriesSampler_few_shot, SamplerQuery_few_shot, SamplerSupport_few_shot
 from src.task_generator_few_shot import relabel
 from src.utils import Logger, compute_confidence_interval
@@ -33,7 +34,7 @@ def relabel_batch(x_s, x_q, y_s, y_q, use_softmax_feature):
 
 
 _METHODS = {'EM_DIRICHLET': EM_DIRICHLET, 'HARD_EM_DIRICHLET': HARD_EM_DIRICHLET, 'PADDLE': PADDLE, 'BDCSPN': BDCSPN,
-            'ALPHA_TIM': ALPHA_TIM}
+            'ALPHA_TIM': ALPHA_TIM, 'LAPLACIAN_SHOT': LAPLACIAN_SHOT}
 
 
 class Evaluator_few_shot:

@@ -37,6 +37,9 @@ _SIGNATURES = {
     "tclip_paddle_run": (ctypes.c_int, [ctypes.POINTER(Problem), _P, _P, _P, ctypes.c_float, _P, _P, _P, _P, _P, ctypes.c_size_t, _P]),
     "tclip_alpha_tim_workspace_bytes": (ctypes.c_size_t, [ctypes.POINTER(Problem)]),
     "tclip_alpha_tim_run": (ctypes.c_int, [ctypes.POINTER(Problem), ctypes.POINTER(TimParams)] + [_P] * 8 + [ctypes.c_size_t, _P]),
+    "tclip_laplacian_shot_workspace_bytes": (ctypes.c_size_t, [ctypes.POINTER(Problem)]),
+    "tclip_laplacian_shot_run": (ctypes.c_int, [ctypes.POINTER(Problem), _P, _P, _P, ctypes.c_int32, ctypes.c_double, ctypes.c_int32,
+                                                _P, _P, _P, _P, _P, ctypes.c_size_t, _P]),
     "tclip_bdcspn_workspace_bytes": (ctypes.c_size_t, [ctypes.POINTER(Problem)]),
     "tclip_bdcspn_run": (ctypes.c_int, [ctypes.POINTER(Problem), _P, _P, _P, ctypes.c_float, ctypes.c_int32, _P, _P, _P, _P, ctypes.c_size_t, _P]),
     "tclip_hard_kmeans_workspace_bytes": (ctypes.c_size_t, [ctypes.POINTER(Problem)]),

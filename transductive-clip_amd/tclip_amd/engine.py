@@ -183,6 +183,23 @@ def run_alpha_tim(x_q, x_s, y_s, *, iters, temp, lr, alpha_value, loss_weights=(
     return weights, logits_q, preds, crit
 
 
+def run_laplacian_shot(x_q, x_s, y_s, *, iters, knn, lmd, norm_type="L2N"):
+    """LAPLACIAN_SHOT: x_q (T,Q,K), x_s (T,S,K) f32 cuda, y_s (T,S) int64 cuda -> (unary (T,Q,K), neighbours (T,Q,knn-1) i32,
+    preds_iter (T,iters,Q) i32, energies (T,iters) f64), cuda, not synchronised."""
+    if norm_type not in ("UN", "L2N"):
+        raise ValueError("norm_type must be 'UN' or 'L2N' (the reference's CL2N needs a train mean it never passes)")
+    x_q = _query(x_q)
+    x_s, y_s = _support(x_q, x_s, y_s)
+    T, Q, K = x_q.shape
+    c = _Call(x_q.device, _capi.Problem(1, T, Q, K, x_s.shape[1], iters, 1, 0, 0), "tclip_laplacian_shot_workspace_bytes")
+    unary, nbr = c.empty(T, Q, K), c.empty(T, Q, max(int(knn) - 1, 1), dtype=torch.int32)
+    preds_iter, energies = c.empty(T, max(iters, 1), Q, dtype=torch.int32), c.empty(T, max(iters, 1), dtype=torch.float64)
+    c.launch("tclip_laplacian_shot_run", lambda ws, n, st: (_ptr(x_q), _ptr(x_s), _ptr(y_s), ctypes.c_int32(int(knn)),
+                                                            ctypes.c_double(float(lmd)), ctypes.c_int32(NORM_TYPES[norm_type]),
+                                                            _ptr(unary), _ptr(nbr), _ptr(preds_iter), _ptr(energies), ws, n, st))
+    return unary, nbr, preds_iter, energies
+
+
 def argmax_rows(x):
     """x (..., K) f32 cuda -> int32 (...) indices of the first maximum of every row, cuda, not synchronised."""
     _require_cuda(x, "x")
