@@ -117,3 +117,40 @@ def test_full_evaluation_needs_the_saved_feature_files(tmp_path):
     a.shots, a.use_softmax_feature = 4, False
     with pytest.raises(FileNotFoundError, match="data/dtd/saved_features/train_visual_RN50.plk"):
         Evaluator_few_shot(torch.device("cpu"), a, None).run_full_evaluation(None, None)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("method,param,values", [("alpha_tim", "alpha_value", ("2.0", "5.0", "7.0")),
+                                                 ("laplacian_shot", "lmd", ("0.1", "0.7", "1.5"))])
+def test_cli_tuning_workflow_from_yaml(tmp_path, method, param, values):
+    """main_features.py with the reference-format config tree for the two tunable baselines: validation runs sweep the
+    parameter into results_few_shot/val/, the test run reads the best competing value back and writes its row."""
+    import sys
+    import torch
+    from conftest import PKG
+    from tclip_amd import features, synth
+    sys.path.insert(0, PKG)
+    import main_features
+    K = 10
+    plk = {}
+    for split, seed in (("train", 11), ("val", 12), ("test", 13)):
+        feats, labels = synth.make_feature_table(K, 40, seed=seed)
+        plk[split] = str(tmp_path / f"{split}.plk")
+        features.save_features(plk[split], feats, labels)
+    common = ["--support", plk["train"], "--config-root", CONFIG, "--results-root", str(tmp_path), "--opts", "method", method,
+              "shots", "2", "number_tasks", "8", "batch_size", "4", "save_results", "True"]
+    accs = {}
+    for v in values:
+        acc, _, path = main_features.main(["--query", plk["val"]] + common + ["used_test_set", "val", param, v])
+        accs[float(v)] = round(100 * float(acc), 2)
+    rows = open(path).read().splitlines()
+    assert rows[0] == "val_param\tacc" and [float(r.split("\t")[0]) for r in rows[1:]] == [float(v) for v in values]
+    competing = [float(v) for v in values[1:]]
+    best = [v for v in competing if accs[v] == max(accs[c] for c in competing)][-1]
+    acc, _, path = main_features.main(["--query", plk["test"]] + common)
+    assert path.endswith(f"results_few_shot/test/toyset/{method.upper()}_softmax_s2.txt")
+    assert open(path).read().splitlines()[-1].split("\t")[:4] == ["2", "75", "4", str(round(100 * float(acc), 1))]
+    # the run used the tuned value: the same call with the value fixed by hand and tuning off gives the same accuracy
+    acc2, _, _ = main_features.main(["--query", plk["test"]] + common + [param, str(best), "tunable", "False"])
+    assert float(acc2) == float(acc)
+    torch.cuda.synchronize()
