@@ -454,8 +454,10 @@ def run_laplacian_shot(x_q, x_s, y_s, y_q, *, n_class, iters, knn, lmd, norm_typ
     from sklearn.neighbors import NearestNeighbors
     z_s, z_q = x_s.clone().float().cpu(), x_q.clone().float().cpu()
     if norm_type == "L2N":
-        z_s = z_s / LA.norm(z_s, 2, 2)[:, :, None]
-        z_q = z_q / LA.norm(z_q, 2, 2)[:, :, None]
+        # the reference divides the torch tensor by LA.norm's numpy result (:84-85); same numbers without numpy's
+        # __array_wrap__ deprecation warning
+        z_s = z_s / torch.from_numpy(LA.norm(z_s.numpy(), 2, 2))[:, :, None]
+        z_q = z_q / torch.from_numpy(LA.norm(z_q.numpy(), 2, 2))[:, :, None]
     n_task = z_q.shape[0]
     y_s = y_s.long().view(n_task, -1)
     y_q = y_q.long().view(n_task, -1).numpy()

@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""ALPHA_TIM on the GPU: deviations from the reference fixtures and a timing at the reference's default shape."""
+"""ALPHA_TIM and LAPLACIAN_SHOT on the GPU: deviations from the reference fixtures and timings."""
 import glob
 import os
 import sys
@@ -37,3 +37,15 @@ for K, N, shots, iters in ((100, 100, 4, 1000), (10, 100, 4, 1000), (397, 20, 4,
         dt = time.time() - t0
     flop = 4.0 * N * (K * shots + 75) * K * K * iters
     print(f"K={K} N={N} shots={shots} iters={iters}: {dt:.3f} s  ({N / dt:.1f} tasks/s, {flop / dt / 1e12:.2f} TFLOP/s fp32 in the two GEMMs)")
+
+for K, N, shots in ((100, 100, 4), (10, 100, 4), (397, 50, 4), (1000, 20, 4)):
+    x_q, _ = synth.make_query_tasks(N, K, seed=5, k_eff=5)
+    x_s, y_s = synth.make_support(N, K, shots, seed=5)
+    x_q, x_s, y_s = x_q.cuda(), x_s.cuda(), y_s.squeeze(2).cuda()
+    for _ in range(2):
+        torch.cuda.synchronize()
+        t0 = time.time()
+        engine.run_laplacian_shot(x_q, x_s, y_s, iters=20, knn=3, lmd=0.7)
+        torch.cuda.synchronize()
+        dt = time.time() - t0
+    print(f"LAPLACIAN_SHOT K={K} N={N} shots={shots}: {dt * 1e3:.1f} ms  ({N / dt:.0f} tasks/s)")
