@@ -8,6 +8,12 @@ src/utils.py:266-267) can run the task loop from them:
     python main_features.py --query test_softmax_RN50_T30.plk [--support train_softmax_RN50_T30.plk] \\
         --opts method em_dirichlet dataset caltech101 number_tasks 1000 batch_size 100 shots 0
 
+Without `--query` the files are looked up where the reference keeps them, as `main.py` does once the features exist:
+<results-root>/data/<dataset>/saved_features/<used_test_set>_softmax_<backbone>_T<T>.plk (and train_... for the
+support set of a few-shot run):
+
+    python main_features.py --opts dataset food101 method paddle shots 4 number_tasks 1000 batch_size 100
+
 Configuration follows main.py:19-35: with `--config-root DIR` (or a `config/` directory in the working
 directory) the reference-format YAML files are read - DIR/main_config.yaml, then `--opts`, then
 DIR/datasets_config/config_<dataset>.yaml and DIR/methods_config/<method>.yaml, then `--opts` again, so
@@ -56,7 +62,8 @@ METHOD_DEFAULTS = {
 
 def parse_args(argv=None):
     ap = argparse.ArgumentParser(description=__doc__.split("\n")[0])
-    ap.add_argument("--query", required=True, help="feature pickle of the query/test split")
+    ap.add_argument("--query", default=None, help="feature pickle of the query/test split (default: the reference's "
+                                                  "data/<dataset>/saved_features/ layout under --results-root)")
     ap.add_argument("--support", default=None, help="feature pickle of the support/train split (few-shot)")
     ap.add_argument("--results-root", default=".")
     ap.add_argument("--config-root", default=None, help="directory with main_config.yaml, datasets_config/, methods_config/ "
@@ -93,15 +100,23 @@ def main(argv=None):
     if dist_on:
         import torch.distributed as dist
         dist.init_process_group("nccl", device_id=device)
-    feats_q, labels_q = features.load_features(ns.query)
+    if ns.support is not None and ns.query is None:
+        raise SystemExit("--support needs --query (or give neither and use the data/<dataset>/saved_features/ layout)")
+    query_path = ns.query or reporting.saved_feature_path(args, args.used_test_set, ns.results_root)
+    if not os.path.exists(query_path):
+        raise SystemExit(f"{query_path} not found: extract the features with the reference first (CLIP is out of scope here)")
+    feats_q, labels_q = features.load_features(query_path)
     args.num_classes_test = int(feats_q.shape[1]) if args.use_softmax_feature else int(labels_q.max()) + 1
     args.n_class = args.num_classes_test
     logger = Logger(__name__, None)
     if int(args.shots) > 0:
         from src.eval_few_shot import Evaluator_few_shot
-        if ns.support is None:
+        support_path = ns.support or (reporting.saved_feature_path(args, "train", ns.results_root) if ns.query is None else None)
+        if support_path is None:
             raise SystemExit("few-shot evaluation needs --support")
-        feats_s, labels_s = features.load_features(ns.support)
+        if not os.path.exists(support_path):
+            raise SystemExit(f"{support_path} not found: extract the features with the reference first")
+        feats_s, labels_s = features.load_features(support_path)
         ev = Evaluator_few_shot(device=device, args=args, log_file=None)
         acc, t = ev.evaluate_tasks(None, feats_s, labels_s, feats_q, labels_q)
     else:
