@@ -79,3 +79,21 @@ def test_argument_errors():
         engine.run_laplacian_shot(x_q.cuda(), x_s.cuda(), y_s.squeeze(2).cuda(), iters=3, knn=1, lmd=0.7)
     with pytest.raises(RuntimeError, match="iters"):
         engine.run_laplacian_shot(x_q.cuda(), x_s.cuda(), y_s.squeeze(2).cuda(), iters=0, knn=3, lmd=0.7)
+
+
+@pytest.mark.gpu
+def test_nan_features_stay_in_bounds():
+    """A zero query row has no L2 norm: its distances are NaN in the reference too.  The call must come back (neighbour
+    lists inside the task, assignments inside 0..K-1) and leave the other tasks untouched."""
+    from tclip_amd import engine, synth
+    K, N = 12, 3
+    x_q, _ = synth.make_query_tasks(N, K, seed=5, k_eff=4)
+    x_s, y_s = synth.make_support(N, K, 2, seed=5)
+    clean = engine.run_laplacian_shot(x_q.cuda(), x_s.cuda(), y_s.squeeze(2).cuda(), iters=10, knn=3, lmd=0.7)
+    x_bad = x_q.clone()
+    x_bad[1, 7] = 0.0
+    unary, nbr, preds_iter, e = engine.run_laplacian_shot(x_bad.cuda(), x_s.cuda(), y_s.squeeze(2).cuda(), iters=10, knn=3, lmd=0.7)
+    torch.cuda.synchronize()
+    assert int(nbr.min()) >= 0 and int(nbr.max()) < 75 and int(preds_iter.min()) >= 0 and int(preds_iter.max()) < K
+    for k in (0, 2):
+        assert torch.equal(preds_iter[k], clean[2][k]) and torch.equal(e[k], clean[3][k])
