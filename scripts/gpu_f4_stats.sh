@@ -1,0 +1,15 @@
+#!/bin/bash
+# kernel-time breakdown of ALPHA_TIM and LAPLACIAN_SHOT (scripts/gpu_tim_check.py) -> gpurun_out/prof_f4.kernel_stats.csv
+cd /tmp && export TMPDIR=/tmp
+R=$GRAFT_REPO_ROOT
+OUT=$R/gpurun_out/prof_f4
+timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT -- python3 $R/scripts/gpu_tim_check.py > $OUT.log 2>&1
+find $OUT -name "*kernel_stats.csv" | head -1 | xargs -I{} cp {} $OUT.kernel_stats.csv
+rm -rf $OUT
+grep "K=" $OUT.log | cut -c1-150
+python3 - $OUT.kernel_stats.csv <<'PY'
+import csv,sys
+rows=list(csv.DictReader(open(sys.argv[1])))
+for r in rows[:14]:
+    print(r['Name'][:60].ljust(60), r['Calls'].rjust(6), f"{float(r['TotalDurationNs'])/1e6:10.1f} ms  avg {float(r['AverageNs'])/1e3:10.1f} us  {float(r['Percentage']):6.2f}%")
+PY
