@@ -146,13 +146,28 @@ LARGE = {
     "fs_soft_K1000_N1_s1": ("fs_soft", 1000, 1, 20, 1, 2063, False),
     # three tasks coupled by the MM stop test at K = 1000: the reference's fp32 norm runs over 3e6 elements per checkpoint
     "zs_soft_K1000_N3": ("zs_soft", 1000, 3, 20, 0, 2064, False),
+    # a batch of MORE than 16 384 (task, class) rows: the engine sums the stop test's row terms in two stages there
+    # (k_mm_decide_partial), which is the path every batch of the K = 1000 bench takes.  The reference's (N,Q,K,K)
+    # temporary is 510 MB.  Inputs from tests/helpers/intsynth.py (integer draws + one division: the test regenerates
+    # them, the fixture holds their digest), outputs as digests + samples ("lean").
+    "bigbatch_zs_soft_K100_N170": ("zs_soft", 100, 170, 20, 0, 2080, False),
 }
+INTSYNTH_LEAN = {"bigbatch_zs_soft_K100_N170"}
+LEAN_BOOST = 64          # soft rows: the first outer iteration of the 170-task batch stops at MM iteration 151 (boost 4096: never)
 
 
 def run_case(name, spec, classes):
     kind, K, N, iters, shots, seed, full = spec
     few = kind.startswith("fs")
-    x_q, y_q = synth.make_query_tasks(N, K, seed=seed, k_eff=(5 if few else None))
+    lean = name in INTSYNTH_LEAN
+    if lean:
+        sys.path.insert(0, os.path.join(ROOT, "tests"))
+        from helpers import intsynth
+        sys.path.pop(0)
+        xq_np, yq_np = intsynth.make_tasks(seed, N, K, 75, boost=LEAN_BOOST)
+        x_q, y_q = torch.from_numpy(xq_np), torch.from_numpy(yq_np).unsqueeze(2)
+    else:
+        x_q, y_q = synth.make_query_tasks(N, K, seed=seed, k_eff=(5 if few else None))
     task = {"x_q": x_q.clone(), "y_q": y_q.clone()}
     if few:
         x_s, y_s = synth.make_support(N, K, shots, seed=seed)
@@ -241,7 +256,23 @@ def run_case(name, spec, classes):
         out["x_s"], out["y_s"] = x_s.numpy(), y_s.numpy()
     if kind == "zs_emgc":
         out["s"] = m.s.numpy()        # inverse diagonal covariances
-    if full:
+    if lean:
+        import hashlib
+        sha = lambda a: hashlib.sha1(np.ascontiguousarray(a).tobytes()).hexdigest()      # noqa: E731
+        del out["x_q"]
+        out["inputs"] = "intsynth"
+        out["boost"] = LEAN_BOOST
+        out["x_q_sha1"] = sha(x_q.numpy())
+        out["u_sha1"] = sha(m.u.numpy())
+        out["alpha_sha1"] = sha(alpha)
+        rng = np.random.default_rng(seed)
+        rows = np.stack([np.sort(rng.choice(K, size=8, replace=False)) for _ in range(N)])
+        out["alpha_rows_idx"] = rows.astype(np.int32)
+        out["alpha_rows"] = np.stack([alpha[n, rows[n]] for n in range(N)])
+        a64 = alpha.astype(np.float64)
+        out["alpha_rowsum"] = a64.sum(-1)
+        out["alpha_rowsumsq"] = (a64 * a64).sum(-1)
+    elif full:
         out["alpha"] = alpha
         out["u"] = m.u.numpy()
     else:

@@ -13,8 +13,9 @@ def simplex_rows(rng, labels, n_class, boost=4096):
     return (raw / raw.sum(1, keepdims=True)).astype(np.float32)
 
 
-def make_tasks(seed, n_task, n_class, n_query=75, shots=0):
-    """x_q (N,Q,K) f32, y_q (N,Q) i64 [, x_s (N,K*shots,K) f32, y_s (N,K*shots) i64]"""
+def make_tasks(seed, n_task, n_class, n_query=75, shots=0, boost=4096):
+    """x_q (N,Q,K) f32, y_q (N,Q) i64 [, x_s (N,K*shots,K) f32, y_s (N,K*shots) i64].  `boost`: how far the labelled
+    class stands out (4096: near one-hot rows; 64: soft rows on which the MM loop of a large batch still converges early)"""
     rng = np.random.default_rng(seed)
     x_q = np.empty((n_task, n_query, n_class), np.float32)
     y_q = np.empty((n_task, n_query), np.int64)
@@ -22,9 +23,9 @@ def make_tasks(seed, n_task, n_class, n_query=75, shots=0):
         k_eff = int(rng.integers(min(3, n_class), min(10, n_class) + 1))
         classes = rng.permutation(n_class)[:k_eff]
         y = classes[rng.integers(0, k_eff, size=n_query)]
-        x_q[t], y_q[t] = simplex_rows(rng, y, n_class), y
+        x_q[t], y_q[t] = simplex_rows(rng, y, n_class, boost), y
     if not shots:
         return x_q, y_q
     y_s = np.repeat(np.arange(n_class), shots)
-    x_s = np.stack([simplex_rows(rng, y_s, n_class) for _ in range(n_task)])
+    x_s = np.stack([simplex_rows(rng, y_s, n_class, boost) for _ in range(n_task)])
     return x_q, y_q, x_s, np.tile(y_s, (n_task, 1))

@@ -1,8 +1,11 @@
 """ALPHA_TIM: the torch-autograd oracle against the golden vectors produced by the reference's class
 (CPU), and the HIP path (closed-form gradient) against the same vectors (GPU).  The reference's MKL matmuls and
 autograd accumulation leave no operation order to reproduce, and Adam normalises every coordinate's step, so the
-comparison carries a tolerance: weights to max(2e-4, lr) absolute (they move by up to iter * lr = 0.1 … 0.3), query logits to 2e-2
-of their 1e1..1e2 range, per-step criterions to 1 %, and the accuracies equal on all but near-tied queries."""
+comparison carries a tolerance.  GPU path: per-fixture bounds at twice the deviation measured on MI355X
+(tests/golden/f4_tolerances.json; weights 1e-6 .. 3.5e-4 absolute, query logits 2e-5 .. 2.5e-3, criterions 1e-5 .. 6.4e-4
+relative), predictions and accuracies equal.  CPU oracle on a host other than the fixtures': weights to max(2e-4, lr)
+(they move by up to iter * lr = 0.1 ... 0.3), logits to 2e-2 of their 1e1..1e2 range, criterions to 1 %."""
+import json
 import os
 
 import numpy as np
@@ -37,13 +40,20 @@ def test_oracle_reproduces_reference(name):
     assert np.abs(acc.numpy() - g["acc"]).max() <= 2 / 75 + 1e-6
 
 
-def _check(weights, logits_q, crit, g):
+GPU_BOUNDS = json.load(open(os.path.join(GOLDEN, "f4_tolerances.json")))["alpha_tim"]
+
+
+def _check(weights, logits_q, crit, g, bounds=None):
+    """bounds=None: the host-to-host tolerance of the CPU oracle; else the fixture's entry of f4_tolerances.json"""
     w_err = np.abs(weights - g["weights"]).max()
-    w_tol = max(2e-4, float(g["lr"]))          # one Adam step of the fixture's learning rate, at least 2e-4
-    assert w_err < w_tol, f"weights differ by {w_err}"
+    w_tol = bounds["weights_abs"] if bounds else max(2e-4, float(g["lr"]))   # one Adam step of the fixture's learning rate, at least 2e-4
+    assert w_err <= w_tol, f"weights differ by {w_err} (bound {w_tol})"
     l_err = np.abs(logits_q - g["logits_q"]).max()
-    assert l_err < 2e-2, f"query logits differ by {l_err}"
-    assert np.allclose(crit, g["criterions"], rtol=1e-2, atol=1e-7), np.abs(crit / g["criterions"] - 1).max()
+    l_tol = bounds["logits_abs"] if bounds else 2e-2
+    assert l_err <= l_tol, f"query logits differ by {l_err} (bound {l_tol})"
+    c_err = np.abs(crit / g["criterions"] - 1).max()
+    c_tol = bounds["criterions_rel"] if bounds else 1e-2
+    assert c_err <= c_tol, f"criterions differ by {c_err} relative (bound {c_tol})"
 
 
 @pytest.mark.gpu
@@ -59,13 +69,12 @@ def test_engine_matches_reference(name):
     m = ALPHA_TIM(model=None, device=torch.device("cuda:0"), log_file=None, args=a)
     logs = m.run_task(task_dic={"x_q": torch.from_numpy(g["x_q"]), "y_q": torch.from_numpy(g["y_q"]),
                                 "x_s": torch.from_numpy(g["x_s"]), "y_s": torch.from_numpy(g["y_s"])}, shot=int(g["shots"]))
-    _check(m.weights.cpu().numpy(), m.logits_q.cpu().numpy(), logs["criterions"], g)
+    assert name in GPU_BOUNDS, "every ALPHA_TIM fixture has its measured bound in tests/golden/f4_tolerances.json"
+    _check(m.weights.cpu().numpy(), m.logits_q.cpu().numpy(), logs["criterions"], g, GPU_BOUNDS[name])
     assert logs["criterions"].shape == g["criterions"].shape and logs["acc"].shape == g["acc"].shape
-    # predictions: equal wherever the reference's top two logits are more than the tolerance apart
-    top2 = np.sort(g["logits_q"], axis=2)[:, :, -2:]
-    clear = (top2[:, :, 1] - top2[:, :, 0]) > 4e-2
-    assert np.array_equal(m.preds.cpu().numpy()[clear], g["logits_q"].argmax(2)[clear])
-    assert np.abs(logs["acc"] - g["acc"]).max() <= (~clear).sum(1).max() / 75 + 1e-6
+    # everything discrete is equal: every prediction and every accuracy
+    assert np.array_equal(m.preds.cpu().numpy(), g["logits_q"].argmax(2)), "predictions differ from the reference's"
+    assert np.array_equal(logs["acc"], g["acc"]), "accuracies differ from the reference's"
 
 
 @pytest.mark.gpu

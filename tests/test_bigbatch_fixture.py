@@ -1,0 +1,26 @@
+"""CPU: the lean big-batch fixture (tests/golden/bigbatch_*.npz, made by running the reference on a 170-task batch) is
+reproducible here - its inputs come back from the integer generator bit for bit - and the C++ oracle takes the
+reference's first outer iteration on it: the early stop at MM iteration 151 of a 17 000-row batch and the same argmax.
+(The whole 20 x 1000 schedule is the GPU test's job, tests/test_gpu_round3.py.)"""
+import hashlib
+import os
+
+import numpy as np
+
+from conftest import GOLDEN
+from helpers import intsynth
+from oracle import c_oracle
+
+
+def test_bigbatch_fixture_inputs_and_first_iteration():
+    g = np.load(os.path.join(GOLDEN, "bigbatch_zs_soft_K100_N170.npz"))
+    K, N = int(g["K"]), int(g["N"])
+    assert N * K > 16384 and str(g["inputs"]) == "intsynth"
+    x_q, y_q = intsynth.make_tasks(int(g["seed"]), N, K, 75, boost=int(g["boost"]))
+    assert hashlib.sha1(np.ascontiguousarray(x_q).tobytes()).hexdigest() == str(g["x_q_sha1"])
+    assert np.array_equal(y_q, g["y_q"].reshape(N, 75))
+    assert g["mm_iters"][0] == 151 and (g["mm_iters"][1:] == 1000).all()       # one early stop, 19 x 19 decisions not to
+    ref = c_oracle.run(x_q, iters=1, iter_mm=1000, lambd=int(K / 5) * 75)
+    assert ref["mm_iters"][0] == g["mm_iters"][0]
+    assert np.array_equal(ref["argmax"][0], g["argmax"][0])
+    assert ref["criterions"][0] == g["criterions"][0]

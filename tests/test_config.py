@@ -150,7 +150,31 @@ def test_cli_tuning_workflow_from_yaml(tmp_path, method, param, values):
     acc, _, path = main_features.main(["--query", plk["test"]] + common)
     assert path.endswith(f"results_few_shot/test/toyset/{method.upper()}_softmax_s2.txt")
     assert open(path).read().splitlines()[-1].split("\t")[:4] == ["2", "75", "4", str(round(100 * float(acc), 1))]
-    # the run used the tuned value: the same call with the value fixed by hand and tuning off gives the same accuracy
-    acc2, _, _ = main_features.main(["--query", plk["test"]] + common + [param, str(best), "tunable", "False"])
-    assert float(acc2) == float(acc)
+    # The reference builds batch 0's method BEFORE it reads the sweep file (eval_few_shot.py:250-254) and the methods copy
+    # their parameter in __init__: batch 0 runs with the YAML default, batch 1 with the tuned value.  Reproduced by default;
+    # per-batch accuracies of hand-fixed runs tell the two halves apart.
+    from src import eval_few_shot
+    per_batch = {}
+    real = eval_few_shot.Evaluator_few_shot.evaluate_tasks
+
+    def spy(self, *a, **k):
+        r = real(self, *a, **k)
+        per_batch["last"] = self.last_task_accuracies.copy()
+        return r
+    eval_few_shot.Evaluator_few_shot.evaluate_tasks = spy
+    try:
+        main_features.main(["--query", plk["test"]] + common)
+        quirk = per_batch["last"]
+        main_features.main(["--query", plk["test"]] + common + ["tunable", "False"])                       # YAML default everywhere
+        default = per_batch["last"]
+        acc2, _, _ = main_features.main(["--query", plk["test"]] + common + [param, str(best), "tunable", "False"])    # best everywhere
+        fixed = per_batch["last"]
+        acc3, _, _ = main_features.main(["--query", plk["test"]] + common + ["tuned_param_for_every_batch", "True"])
+        every = per_batch["last"]
+    finally:
+        eval_few_shot.Evaluator_few_shot.evaluate_tasks = real
+    assert quirk.shape == (2, 4)
+    assert np.array_equal(quirk[0], default[0]) and np.array_equal(quirk[1], fixed[1])
+    # tuned_param_for_every_batch: the tuned value from batch 0 on = the value fixed by hand with tuning off
+    assert np.array_equal(every, fixed) and float(acc3) == float(acc2)
     torch.cuda.synchronize()

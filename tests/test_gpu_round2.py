@@ -114,7 +114,9 @@ def _rank_main(rank, world, port, name, out):
         ev = Evaluator_few_shot(torch.device(DEV), a, None)
         acc, _ = ev.evaluate_tasks(None, fs, ls, feats, labels)
     if rank == 0:
-        np.save(out, ev.last_task_accuracies)
+        # everything the one collective carries: accuracies, per-task predictions, per-batch criterions and MM counts
+        np.savez(out, acc=ev.last_task_accuracies, preds=ev.last_task_predictions, criterions=ev.last_batch_criterions,
+                 mm_iters=ev.last_batch_mm_iters)
         assert abs(float(acc) - float(g["mean_accuracy"])) < 1e-7
     else:
         assert acc is None
@@ -126,15 +128,22 @@ def _rank_main(rank, world, port, name, out):
                                         ("eval_fs_soft_K10", 2)])
 def test_task_batch_loop_is_world_size_independent(name, world, tmp_path):
     """evaluate_tasks under 1, 2 and 3 ranks (more ranks than batches included): rank 0 ends up with the
-    same per-task accuracies, bit for bit, and the reference's mean accuracy."""
+    same per-task accuracies, per-task predictions, per-batch criterions and MM counts, bit for bit, and the
+    reference's mean accuracy."""
     import torch.multiprocessing as mp
     outs = []
     for w in (1, world) if world > 1 else (1,):
-        out = str(tmp_path / f"acc_{w}.npy")
+        out = str(tmp_path / f"gathered_{w}.npz")
         mp.spawn(_rank_main, args=(w, 29600 + (os.getpid() + 7 * w) % 2000, name, out), nprocs=w, join=True)
-        outs.append(np.load(out))
+        outs.append(dict(np.load(out)))
+    g = np.load(os.path.join(GOLDEN, name + ".npz"))
+    n_batches, N = int(g["number_tasks"]) // int(g["batch_size"]), int(g["batch_size"])
+    assert outs[0]["preds"].shape == (n_batches, N, 75) and outs[0]["preds"].dtype == np.int32
+    assert outs[0]["criterions"].shape == (n_batches, 20) and outs[0]["mm_iters"].shape == (n_batches, 20)
+    assert (outs[0]["mm_iters"] >= 51).all() and (outs[0]["criterions"] > 0).any()
     for o in outs[1:]:
-        assert np.array_equal(o, outs[0])
+        for k in ("acc", "preds", "criterions", "mm_iters"):
+            assert np.array_equal(o[k], outs[0][k]), k
 
 
 # ---- bounded random sweep (the large campaigns live in scripts/gpu_fuzz.py)

@@ -1,0 +1,104 @@
+"""GPU (round 3): the stop-test path the headline bench runs.
+
+The reference's MM stop test is ONE norm over the whole (N,K,K) batch tensor (em_dirichlet.py:169-175).  For batches of
+more than 16 384 (task, class) rows the engine sums the rows' fp64 terms in two stages: 64 slices per batch by
+`k_mm_decide_partial`, then the slices in order by `k_mm_decide` (csrc/tclip_kernels.hip, `two_stage`).  Every batch
+of the K = 1000 bench (125 tasks x 1000 classes = 125 000 rows) takes that path; the tests here are the ones that reach it:
+
+* `bigbatch_zs_soft_K100_N170` - a fixture made by RUNNING THE REFERENCE on a 170-task batch (17 000 rows, full
+  20 x 1000 schedule, tests/golden/make_golden.py), inputs regenerated from integer draws, outputs as digests + samples;
+* K = 397 x 42 tasks (16 674 rows, 32 lanes per row) and K = 1000 x 17 tasks (17 000 rows, one wavefront per row)
+  against the C++ oracle, alone and as three batches in one call (three stream groups at K = 1000).
+"""
+import hashlib
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import GOLDEN
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+TWO_STAGE_MIN_ROWS = 16384          # csrc/tclip_kernels.hip: `two_stage = has_check && N * K > 16384`
+
+
+def _sha(a):
+    return hashlib.sha1(np.ascontiguousarray(a).tobytes()).hexdigest()
+
+
+def test_two_stage_stop_test_matches_reference_bigbatch():
+    """k_mm_decide_partial + k_mm_decide against the reference itself: every `crit < 1e-11` decision of a 17 000-row batch
+    (the MM iteration counts), and through them every bit of alpha, u and v."""
+    from helpers import intsynth
+    from tclip_amd import engine
+    g = np.load(os.path.join(GOLDEN, "bigbatch_zs_soft_K100_N170.npz"))
+    K, N, iters = int(g["K"]), int(g["N"]), int(g["iters"])
+    assert N * K > TWO_STAGE_MIN_ROWS, "the fixture must reach the two-stage stop test"
+    x_q, y_q = intsynth.make_tasks(int(g["seed"]), N, K, 75, boost=int(g["boost"]))
+    assert _sha(x_q) == str(g["x_q_sha1"]), "input generator is not reproducible on this host"
+    assert np.array_equal(y_q, g["y_q"].reshape(N, 75))
+    # the reference's recorded decisions are consistent with its MM counts and none sits where fp64 and fp32 sums could disagree
+    st = g["stop_test"].astype(np.float32)
+    with np.errstate(invalid="ignore", divide="ignore"):
+        crit = (st[:, :, 0] ** 2) / (st[:, :, 1] ** 2)
+    seen = ~np.isnan(crit)
+    margin = np.abs(crit[seen].astype(np.float64) / 1e-11 - 1.0)
+    assert margin.min() > 1e-4, f"a recorded stop test sits within {margin.min():.1e} of the threshold"
+    for i, n_mm in enumerate(g["mm_iters"].tolist()):
+        k = int(seen[i].sum())
+        stopped = k > 0 and crit[i, k - 1] < np.float32(1e-11)
+        assert n_mm == (50 * k + 1 if stopped else int(g["iter_mm"])), (i, n_mm, k)
+    assert (g["mm_iters"] < int(g["iter_mm"])).any(), "the fixture should contain an early stop decided by the two-stage sum"
+
+    x = torch.from_numpy(x_q).to(DEV)
+    res = engine.run_em_dirichlet(x, n_batches=1, iters=iters, iter_mm=int(g["iter_mm"]), lambd=int(K / 5) * 75, hard=False)
+    torch.cuda.synchronize()
+    assert np.array_equal(res.mm_iters.cpu().numpy()[0], g["mm_iters"]), "MM iteration counts differ from the reference's"
+    assert np.array_equal(res.preds.cpu().numpy(), g["argmax"][-1].astype(np.int32))
+    alpha = res.alpha.cpu().numpy()
+    rows = g["alpha_rows_idx"]
+    sampled = np.stack([alpha[n, rows[n]] for n in range(N)])
+    assert np.array_equal(sampled, g["alpha_rows"]), "sampled alpha rows differ"
+    a64 = alpha.astype(np.float64)
+    np.testing.assert_allclose(a64.sum(-1), g["alpha_rowsum"], rtol=1e-12)
+    np.testing.assert_allclose((a64 * a64).sum(-1), g["alpha_rowsumsq"], rtol=1e-12)
+    assert _sha(alpha) == str(g["alpha_sha1"]), "alpha differs from the reference's"
+    assert _sha(res.u.cpu().numpy()) == str(g["u_sha1"]), "responsibilities differ from the reference's"
+    assert np.array_equal(res.v.cpu().numpy(), g["v"])
+    assert np.array_equal(res.criterions.cpu().numpy()[0], g["criterions"])
+    acc_t, _ = engine.clustering_accuracy(x, res.preds, torch.from_numpy(y_q))
+    assert np.array_equal(acc_t.numpy().reshape(-1, 1), g["acc"])
+
+
+@pytest.mark.parametrize("K,N", [(397, 42), (1000, 17)])
+def test_two_stage_stop_test_equals_oracle_and_is_grouping_free(K, N):
+    """Batches just over 16 384 rows (iters 2, iter_mm 101: two checkpoints per outer iteration) against the C++ oracle,
+    then three such batches in ONE call (K = 1000: 51 000 rows -> three stream groups; K = 397: two) against each batch
+    alone: k_mm_decide_partial's slices and the stream split are invisible in the results."""
+    from oracle import c_oracle
+    from tclip_amd import engine, synth
+    assert N * K > TWO_STAGE_MIN_ROWS
+    B, kw = 3, dict(iters=2, iter_mm=101, lambd=int(K / 5) * 75, hard=False)
+    x_q, _ = synth.make_query_tasks(B * N, K, seed=7000 + K)
+    x = x_q.to(DEV)
+    full = engine.run_em_dirichlet(x, n_batches=B, **kw)
+    torch.cuda.synchronize()
+    c_oracle.lib().tclip_oracle_min_stop_margin.restype = __import__("ctypes").c_double
+    c_oracle.lib().tclip_oracle_min_stop_margin(1)
+    for b in range(B):
+        sl = slice(b * N, (b + 1) * N)
+        single = engine.run_em_dirichlet(x[sl], n_batches=1, **kw)
+        for name in ("alpha", "u", "v", "preds"):
+            assert torch.equal(getattr(full, name)[sl], getattr(single, name)), (b, name)
+        assert torch.equal(full.mm_iters[b], single.mm_iters[0]) and torch.equal(full.criterions[b], single.criterions[0])
+        if b == 0:                                   # the oracle costs N * K^2 * 202 element-updates on the host: one batch
+            ref = c_oracle.run(x_q[sl].numpy(), iters=kw["iters"], iter_mm=kw["iter_mm"], lambd=kw["lambd"])
+            assert np.array_equal(single.mm_iters[0].cpu().numpy(), ref["mm_iters"])
+            assert np.array_equal(single.alpha.cpu().numpy(), ref["alpha"]), "alpha differs from the oracle's"
+            assert np.array_equal(single.u.cpu().numpy(), ref["u"]) and np.array_equal(single.v.cpu().numpy(), ref["v"])
+            assert np.array_equal(single.criterions[0].cpu().numpy(), ref["criterions"])
+            assert np.array_equal(single.preds.cpu().numpy(), ref["argmax"][-1].astype(np.int32))
+            # (c) no stop test of this run sits where the engine's two-stage fp64 sum and the oracle's serial one could decide differently
+            assert c_oracle.lib().tclip_oracle_min_stop_margin(0) > 1e-6

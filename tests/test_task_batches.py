@@ -84,6 +84,66 @@ def test_batch_sharding_two_ranks_gloo(tmp_path):
     assert torch.equal(got, want)
 
 
+def _worker_packed(rank, world, port, out):
+    """the one collective of a step: predictions (int32), accuracies (f32), criterions (f32), MM counts (int32) of every
+    batch of this rank in ONE all_gather block (sharding.gather_packed); 3 ranks, 4 batches: rank 2 holds one batch"""
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    n_batches, N, Q, iters = 4, 3, 5, 6
+    calls = []
+    real = dist.all_gather
+    dist.all_gather = lambda *a, **k: (calls.append(1), real(*a, **k))[1]
+    mine = sharding.my_batches(n_batches)
+    parts = {"preds": torch.stack([_packed_want(n_batches, N, Q, iters)["preds"][b] for b in mine]),
+             "acc": torch.stack([_packed_want(n_batches, N, Q, iters)["acc"][b] for b in mine]),
+             "criterions": torch.stack([_packed_want(n_batches, N, Q, iters)["criterions"][b] for b in mine]),
+             "mm_iters": torch.stack([_packed_want(n_batches, N, Q, iters)["mm_iters"][b] for b in mine])}
+    got = sharding.gather_packed(parts, n_batches)
+    assert len(calls) == 1, "exactly one collective"
+    if rank == 0:
+        torch.save(got, out)
+    else:
+        assert got is None
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def _packed_want(n_batches, N, Q, iters):
+    g = torch.Generator().manual_seed(5)
+    return {"preds": torch.randint(0, 1000, (n_batches, N * Q), generator=g, dtype=torch.int32),
+            "acc": torch.rand(n_batches, N, generator=g),
+            "criterions": torch.rand(n_batches, iters, generator=g) * 1e-3,
+            "mm_iters": torch.randint(51, 1001, (n_batches, iters), generator=g, dtype=torch.int32)}
+
+
+def test_packed_gather_three_ranks_gloo(tmp_path):
+    out = str(tmp_path / "packed.pt")
+    mp.spawn(_worker_packed, args=(3, 29500 + ((os.getpid() + 313) % 2000), out), nprocs=3, join=True)
+    got, want = torch.load(out), _packed_want(4, 3, 5, 6)
+    assert sorted(got) == sorted(want)
+    for k in want:
+        assert got[k].dtype == want[k].dtype and torch.equal(got[k], want[k]), k       # bit-cast through int32 and back
+    # one rank, no process group: the same dict comes back in batch order
+    alone = sharding.gather_packed(want, 4, 0, 1)
+    assert all(torch.equal(alone[k], want[k]) for k in want)
+    with pytest.raises(TypeError):
+        sharding.gather_packed({"x": torch.zeros(1, 2, dtype=torch.float64)}, 1, 0, 1)
+
+
+def test_method_parts_of_an_idle_rank_have_the_widths_of_a_busy_one():
+    from types import SimpleNamespace as NS
+    a = NS(name_method="EM_DIRICHLET", iter=20)
+    idle = sharding.method_parts(a, None, None, 0, 4, 75, torch.device("cpu"))
+    assert {k: tuple(v.shape) for k, v in idle.items()} == {"preds": (0, 300), "acc": (0, 4), "criterions": (0, 20), "mm_iters": (0, 20)}
+    m = NS(matched_preds=torch.arange(2 * 4 * 75).view(8, 75), preds=None, criterions_per_batch=np.ones((2, 20), np.float32),
+           mm_iters=np.full((2, 20), 51, np.int32))
+    busy = sharding.method_parts(a, m, {"acc": np.full((8, 1), 0.5, np.float32)}, 2, 4, 75, torch.device("cpu"))
+    assert {k: tuple(v.shape[1:]) for k, v in busy.items()} == {k: tuple(v.shape[1:]) for k, v in idle.items()}
+    assert busy["preds"].dtype == torch.int32 and busy["mm_iters"].dtype == torch.int32
+    b = NS(name_method="SOFT_KMEANS", iter=20)
+    assert sorted(sharding.method_parts(b, None, None, 0, 4, 75, torch.device("cpu"))) == ["acc", "preds"]
+
+
 def _worker_idle_rank(rank, world, port, out):
     """more ranks than batches: the idle rank hands an empty block to the one gather"""
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))

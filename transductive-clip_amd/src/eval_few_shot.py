@@ -142,33 +142,46 @@ class Evaluator_few_shot:
         Q = q_idx.shape[2]
         mine = sharding.my_batches(n_batches)
         K = tab_q.shape[1]
-        # the parameter tuned on the validation split, when the test split is evaluated (eval_few_shot.py:252-254;
-        # the reference re-reads the file for every batch, the value is the same)
-        if getattr(a, 'used_test_set', 'test') == 'test' and getattr(a, 'tunable', False) \
-                and not getattr(a, 'skip_tuned_param', False):
+        # The parameter tuned on the validation split, when the test split is evaluated.  The reference builds the
+        # method of a batch FIRST and reads the sweep file afterwards (eval_few_shot.py:250-254), and every method
+        # copies its parameter in __init__ (paddle.py:26, bdcspn.py:18, tim.py:198, laplacian_shot.py:32): its batch 0
+        # therefore runs with the YAML default and only batches 1.. with the tuned value.  That is reproduced here, so
+        # that result files agree with the reference's; `tuned_param_for_every_batch: True` applies it to batch 0 too.
+        tuned = getattr(a, 'used_test_set', 'test') == 'test' and getattr(a, 'tunable', False) \
+            and not getattr(a, 'skip_tuned_param', False)
+        first_method = None
+        if tuned:
+            if 0 in mine and not getattr(a, 'tuned_param_for_every_batch', False):
+                first_method = self.get_method_builder(model=model, device=self.device, args=a, log_file=self.log_file)
             self.set_method_opt_param()
         method = self.get_method_builder(model=model, device=self.device, args=a, log_file=self.log_file)
-        timestamps = 0.0
-        if mine:
-            si, qi = s_idx[mine].reshape(-1), q_idx[mine].reshape(-1)
-            x_s = engine.gather_rows(tab_s, si).view(len(mine) * N, S, K)
-            x_q = engine.gather_rows(tab_q, qi).view(len(mine) * N, Q, K)
+        timestamps, parts = [], None
+        runs = [(first_method, mine[:1]), (method, mine[1:])] if first_method is not None else [(method, mine)]
+        for m, ids in runs:
+            if not ids:
+                continue
+            si, qi = s_idx[ids].reshape(-1), q_idx[ids].reshape(-1)
+            x_s = engine.gather_rows(tab_s, si).view(len(ids) * N, S, K)
+            x_q = engine.gather_rows(tab_q, qi).view(len(ids) * N, Q, K)
             y_s, y_q = lab_s[si].view(-1, S), lab_q[qi].view(-1, Q)
             # label re-indexing / column permutation of Tasks_Generator_few_shot.get_task, per task
             x_s, x_q, y_s, y_q = relabel_batch(x_s, x_q, y_s, y_q, a.use_softmax_feature)
             # BDCSPN normalises the features in run_task, before run_method (few_shot/bdcspn.py:165-166): run_batch does both
-            run = getattr(method, "run_batch", method.run_method)
-            run(support=x_s, query=x_q, y_s=y_s.to(dev), y_q=y_q.to(dev), n_batches=len(mine))
-            logs = method.get_logs()
-            acc = torch.from_numpy(logs['acc'][:, -1].copy()).view(len(mine), N).to(dev)
-            timestamps = float(logs['timestamps'])
-        else:      # more ranks than batches: this rank only takes part in the gather
-            acc = torch.zeros(0, N, device=dev)
-        acc = sharding.gather_batch_results(acc, n_batches)
+            run = getattr(m, "run_batch", m.run_method)
+            run(support=x_s, query=x_q, y_s=y_s.to(dev), y_q=y_q.to(dev), n_batches=len(ids))
+            logs = m.get_logs()
+            parts = sharding.concat_parts(parts, sharding.method_parts(a, m, logs, len(ids), N, Q, dev))
+            timestamps += [float(logs['timestamps'])] * len(ids)
+        if parts is None:      # more ranks than batches: this rank only takes part in the gather
+            parts = sharding.method_parts(a, None, None, 0, N, Q, dev)
+        got = sharding.gather_packed(parts, n_batches)
         self.last_method = method
-        if acc is None:
+        if got is None:
             return None, None
-        acc = acc.cpu().numpy()
+        acc = got['acc'].numpy()
         results_task = [compute_confidence_interval(acc[b])[0] for b in range(n_batches)]
         self.last_task_accuracies = acc
-        return np.asarray(results_task).mean(), timestamps
+        self.last_task_predictions = got['preds'].view(n_batches, N, Q).numpy()
+        self.last_batch_criterions = got['criterions'].numpy() if 'criterions' in got else None
+        self.last_batch_mm_iters = got['mm_iters'].numpy() if 'mm_iters' in got else None
+        return np.asarray(results_task).mean(), (float(np.mean(timestamps)) if timestamps else 0.0)

@@ -108,15 +108,19 @@ class Evaluator_zero_shot:
             y_q = labels[my_idx.to(labels.device)].view(len(mine) * N, Q)
             method.run_method(query=x_q, y_q=y_q.to(dev), n_batches=len(mine))   # SOFT_KMEANS has no cross-task coupling
             logs = method.get_logs()
-            acc = torch.from_numpy(logs['acc'][:, -1].copy()).view(len(mine), N).to(dev)
+            parts = sharding.method_parts(a, method, logs, len(mine), N, Q, dev)
             timestamps = float(logs['timestamps'])
         else:      # more ranks than batches: this rank only takes part in the gather
-            acc = torch.zeros(0, N, device=dev)
-        acc = sharding.gather_batch_results(acc, n_batches)
+            parts = sharding.method_parts(a, None, None, 0, N, Q, dev)
+        # the one collective: per-task predictions, accuracies and the per-batch records of every rank onto rank 0
+        got = sharding.gather_packed(parts, n_batches)
         self.last_method = method
-        if acc is None:                                             # not rank 0
+        if got is None:                                             # not rank 0
             return None, None
-        acc = acc.cpu().numpy()
+        acc = got['acc'].numpy()
         results_task = [compute_confidence_interval(acc[b])[0] for b in range(n_batches)]
         self.last_task_accuracies = acc
+        self.last_task_predictions = got['preds'].view(n_batches, N, Q).numpy()      # class per query, every batch of the run
+        self.last_batch_criterions = got['criterions'].numpy() if 'criterions' in got else None     # (n_batches, iter)
+        self.last_batch_mm_iters = got['mm_iters'].numpy() if 'mm_iters' in got else None
         return np.asarray(results_task).mean(), timestamps

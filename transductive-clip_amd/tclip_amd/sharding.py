@@ -21,6 +21,74 @@ def my_batches(n_batches, rank=None, world_size=None):
     return list(range(rank, n_batches, world_size))
 
 
+# methods whose engine call keeps per-batch records besides predictions and accuracies
+_PER_BATCH_RECORDS = {'EM_DIRICHLET': ('criterions', 'mm_iters'), 'HARD_EM_DIRICHLET': ('criterions', 'mm_iters'),
+                      'ALPHA_TIM': ('criterions',)}
+
+
+def method_parts(args, method, logs, n_local, N, Q, dev):
+    """This rank's results of one method run over `n_local` batches of N tasks, as the parts gather_packed moves
+    (SURVEY.md section 8e): `preds` (N*Q) int32 - the class assigned to every query, after the cluster-to-class
+    matching for the zero-shot clustering methods, `acc` (N) f32, and for the EM-Dirichlet classes / ALPHA_TIM the
+    per-batch `criterions` (iter) f32 and `mm_iters` (iter) int32.  method=None: a rank without a batch (zero rows of
+    the same widths)."""
+    records = _PER_BATCH_RECORDS.get(getattr(args, 'name_method', None), ())
+    iters = int(getattr(args, 'iter', 0))
+    if method is None:
+        parts = {'preds': torch.zeros(0, N * Q, dtype=torch.int32), 'acc': torch.zeros(0, N)}
+        if 'criterions' in records:
+            parts['criterions'] = torch.zeros(0, iters)
+        if 'mm_iters' in records:
+            parts['mm_iters'] = torch.zeros(0, iters, dtype=torch.int32)
+    else:
+        p = getattr(method, 'matched_preds', None)
+        if p is None:
+            p = method.preds
+        parts = {'preds': p.reshape(n_local, N * Q).to(torch.int32),
+                 'acc': torch.from_numpy(logs['acc'][:, -1].copy()).view(n_local, N).float()}
+        if 'criterions' in records:
+            parts['criterions'] = torch.as_tensor(method.criterions_per_batch, dtype=torch.float32).view(n_local, iters)
+        if 'mm_iters' in records:
+            parts['mm_iters'] = torch.as_tensor(method.mm_iters, dtype=torch.int32).view(n_local, iters)
+    return {k: v.to(dev) for k, v in parts.items()}
+
+
+def concat_parts(a, b):
+    """rows of `a` followed by rows of `b` (two method runs of one rank, in batch order)"""
+    return b if a is None else {k: torch.cat([a[k], b[k]], 0) for k in a}
+
+
+def gather_packed(parts, n_batches, rank=None, world_size=None):
+    """The one collective of a step: every per-batch result of this rank in ONE all_gather.
+
+    parts: dict name -> tensor (n_local_batches, ...) of dtype int32 or float32, rows in my_batches(n_batches) order
+    (per-task predictions (N*Q) int32, accuracies (N) f32, criterions (iters) f32, MM counts (iters) int32 ...).
+    The rows are bit-cast to int32 and laid side by side in one (batches_per_rank, width) block per rank.
+    Returns on rank 0 a dict of (n_batches, ...) CPU tensors in batch order, None elsewhere."""
+    if rank is None:
+        rank, world_size = world()
+    names = sorted(parts)
+    for n in names:
+        if parts[n].dtype not in (torch.int32, torch.float32):
+            raise TypeError(f"gather_packed moves int32 / float32 rows, {n} is {parts[n].dtype}")
+    shapes = {n: tuple(parts[n].shape[1:]) for n in names}
+    widths = {n: int(torch.Size(shapes[n]).numel()) for n in names}
+    n_local = parts[names[0]].shape[0]
+    dev = parts[names[0]].device
+    flat = [parts[n].to(dev).reshape(n_local, widths[n]).contiguous().view(torch.int32) for n in names]
+    local = torch.cat(flat, 1)
+    out = gather_batch_results(local, n_batches, rank, world_size)
+    if out is None:
+        return None
+    out = out.cpu()
+    res, o = {}, 0
+    for n in names:
+        block = out[:, o:o + widths[n]].contiguous()
+        res[n] = block.view(parts[n].dtype).reshape((n_batches,) + shapes[n])
+        o += widths[n]
+    return res
+
+
 def gather_batch_results(local, n_batches, rank=None, world_size=None):
     """local: tensor (n_local_batches, ...) for my_batches(n_batches) in that order.
     Returns on rank 0 the (n_batches, ...) tensor in batch order (None elsewhere).
