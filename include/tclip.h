@@ -253,6 +253,12 @@ int tclip_debug_set_probe_chunks(int32_t chunks);
  * Process-wide; results do not depend on it. */
 int tclip_debug_set_rowset_min_rows(int32_t rows);
 
+/* From the second outer iteration on the live rows run through the class-split MM kernel (k_mm_split: every element
+ * executes only what its value class a+1 < 2.3 / [2.3, 10) / >= 10 needs).  For tests: 0 never uses it, 1 uses it from
+ * the first iteration on, 100 + n from outer iteration n on, negative restores the default rule (n = 1).  Process-wide;
+ * results do not depend on it. */
+int tclip_debug_set_mm_split(int32_t mode);
+
 /* Device self-test (used by tests/test_gpu_primitives.py).  out host [14]:
  *   [0] 1/x: fast exact reciprocal vs IEEE quotient, every float of a binade at 3 exponents
  *   [1] a/b: 2^29 operand pairs            [2] fused digamma(a+1), digamma of row sums vs generic

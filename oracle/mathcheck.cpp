@@ -58,6 +58,52 @@ void mc_lgamma_ge23_f64_form(unsigned int lo_bits, unsigned int hi_bits, unsigne
     }
     out[0] = bad; out[1] = unsure; out[2] = seen; out[3] = need;
 }
+// every float of [1, 10) (and a stretch beyond): the closed form of where digamma's recurrence leaves x against the loop,
+// digamma_xp1 against its two-piece form, and the a > 7 specialisation of the fp64 lgamma against the general one.
+// out[0] = mismatches of x, out[1] = mismatches of digamma, out[2] = mismatches of the lgamma specialisation, out[3] = visited
+void mc_rec_closed_form(unsigned long long* out) {
+    unsigned long long bad_x = 0, bad_psi = 0, bad_lg = 0, seen = 0;
+#pragma omp parallel for reduction(+ : bad_x, bad_psi, bad_lg, seen) schedule(static)
+    for (long long bb = tclip::f32_bits(1.0f); bb < (long long)tclip::f32_bits(24.0f); bb++) {
+        const float x1 = tclip::bits_f32((uint32_t)bb);
+        seen++;
+        const float xc = tclip::digamma_rec_x(x1), xl = tclip::digamma_rec_x_loop(x1);
+        if (tclip::f32_bits(xc) != tclip::f32_bits(xl)) bad_x++;
+        if ((bb & 7) == 0) {            // the functions themselves on every 8th float
+            const float whole = tclip::digamma_pos_f32(x1, tclip::kLogTab);
+            const float pieces = tclip::digamma_after_rec(xc, tclip::digamma_rec_acc(x1), tclip::kLogTab);
+            if (tclip::f32_bits(whole) != tclip::f32_bits(pieces)) bad_psi++;
+            if (x1 > 7.0f) {                          // the no-shift form where it is sure (mc_lgamma_gt7_f64_form sweeps the whole domain)
+                bool s1;
+                const float g1 = tclip::lgamma_sleef_gt7_f64<false>(x1, s1);
+                if (s1 && tclip::f32_bits(g1) != tclip::f32_bits(tclip::lgamma_sleef_ge23<false>(x1))) bad_lg++;
+            }
+        }
+    }
+    out[0] = bad_x; out[1] = bad_psi; out[2] = bad_lg; out[3] = seen;
+}
+// floats with bit patterns lo_bits..hi_bits-1, all in (7, 2^41]: the no-shift fp64 form (lgamma_sleef_gt7_f64, the class-C
+// pass of k_mm_split) against Sleef's double-float form.  out as mc_lgamma_ge23_f64_form.
+void mc_lgamma_gt7_f64_form(unsigned int lo_bits, unsigned int hi_bits, unsigned int stride, unsigned long long* out) {
+    unsigned long long bad = 0, unsure = 0, seen = 0, need = 0;
+#pragma omp parallel for reduction(+ : bad, unsure, seen) reduction(max : need) schedule(static)
+    for (long long bb = lo_bits; bb < (long long)hi_bits; bb += stride) {
+        const float x = tclip::bits_f32((uint32_t)bb);
+        bool sure;
+        const float fast = tclip::lgamma_sleef_gt7_f64<false>(x, sure);
+        const float ref = tclip::lgamma_sleef_ge23<false>(x);
+        seen++;
+        if (!sure) unsure++;
+        if (tclip::f32_bits(fast) != tclip::f32_bits(ref)) {
+            if (sure) bad++;
+            double pd, v;
+            (void)tclip::lgamma_sleef_ge23_f64_core<false, true>(x, pd, v);
+            const unsigned long long d = tclip::f64_distance_from_f32_midpoint(v);
+            need = d > need ? d : need;
+        }
+    }
+    out[0] = bad; out[1] = unsure; out[2] = seen; out[3] = need;
+}
 // checksums of the routines over the self-test's argument streams (see tclip_selftest_inputs.h)
 void mc_checksums(unsigned long long* out) {
     for (int f = 0; f < tclip::kSelfTestFunctions; f++) out[f] = 0;

@@ -158,7 +158,23 @@ inline void mm_step_row(const float* beta, const float* y, float* next, int K) {
 }  // namespace
 
 static double g_min_stop_margin = 1e300;
+// Instrumentation (design studies only, scripts/live_row_cycles.py): when set, every live row's MM trajectory is watched for
+// the first iteration at which its state equals one of the previous `g_cycle_max_period` states (64-bit hashes of the
+// row); g_cycle_out[(it * N*K + row) * 2] = that iteration (or -1), [+1] = the period.
+static int32_t* g_cycle_out = nullptr;
+static int g_cycle_max_period = 0;
+static inline uint64_t row_hash(const float* x, int K) {
+    uint64_t h = 0x9e3779b97f4a7c15ull;
+    for (int d = 0; d < K; d++) {
+        uint32_t b;
+        memcpy(&b, &x[d], 4);
+        h = (h ^ b) * 0x100000001b3ull;
+        h ^= h >> 29;
+    }
+    return h;
+}
 extern "C" {
+void tclip_oracle_set_cycle_probe(int32_t* out, int max_period) { g_cycle_out = out; g_cycle_max_period = max_period; }
 
 // Runs the whole loop for ONE reference batch of n_task tasks.
 //   z        [N,Q,K] probability features (query)
@@ -228,10 +244,28 @@ int tclip_oracle_run(const float* z, const float* xs, const int64_t* ys, int N, 
         memcpy(beta.data(), alpha, NKK * sizeof(float));
         int executed = 0;
         bool result_in_next = true;
+        std::vector<uint64_t> ring;
+        const int P = g_cycle_out ? g_cycle_max_period : 0;
+        if (P) {
+            ring.assign((size_t)N * K * P, 0);
+            for (long row = 0; row < (long)N * K; row++) { g_cycle_out[((size_t)it * N * K + row) * 2] = -1; g_cycle_out[((size_t)it * N * K + row) * 2 + 1] = 0; }
+        }
         for (int l = 0; l < iter_mm; l++) {
 #pragma omp parallel for schedule(static)
-            for (long row = 0; row < (long)N * K; row++)
+            for (long row = 0; row < (long)N * K; row++) {
                 mm_step_row(&beta[row * K], &y[row * K], &next[row * K], K);
+                if (P && (few || live[row]) && g_cycle_out[((size_t)it * N * K + row) * 2] < 0) {
+                    if (l == 0) ring[(size_t)row * P] = row_hash(&beta[row * K], K);          // state 0
+                    const uint64_t h = row_hash(&next[row * K], K);                          // state l + 1
+                    for (int p = 1; p <= P && p <= l + 1; p++)
+                        if (ring[(size_t)row * P + (l + 1 - p) % P] == h) {
+                            g_cycle_out[((size_t)it * N * K + row) * 2] = l + 1;
+                            g_cycle_out[((size_t)it * N * K + row) * 2 + 1] = p;
+                            break;
+                        }
+                    ring[(size_t)row * P + (l + 1) % P] = h;
+                }
+            }
             executed++;
             result_in_next = true;
             if (l > 0 && l % 50 == 0) {

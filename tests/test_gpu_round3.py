@@ -102,3 +102,62 @@ def test_two_stage_stop_test_equals_oracle_and_is_grouping_free(K, N):
             assert np.array_equal(single.preds.cpu().numpy(), ref["argmax"][-1].astype(np.int32))
             # (c) no stop test of this run sits where the engine's two-stage fp64 sum and the oracle's serial one could decide differently
             assert c_oracle.lib().tclip_oracle_min_stop_margin(0) > 1e-6
+
+
+def _set_split(mode):
+    from tclip_amd import _capi
+    _capi.check(_capi.lib().tclip_debug_set_mm_split(mode), "tclip_debug_set_mm_split")
+
+
+@pytest.mark.parametrize("K,N,few,hard", [(5, 6, False, False), (10, 8, False, False), (37, 6, False, True), (100, 12, False, False),
+                                           (100, 3, True, False), (196, 4, False, False), (256, 3, False, False), (300, 3, False, False),
+                                           (397, 4, False, True), (512, 2, False, False), (1000, 5, False, False), (1024, 2, True, False)])
+def test_class_split_kernel_is_invisible(K, N, few, hard):
+    """k_mm_split (every element runs only what its value class a+1 < 2.3 / [2.3, 10) / >= 10 needs, through three dense
+    LDS queues) against k_mm_live on the same problems: never / from the first outer iteration on / the default rule
+    (from the second on) give identical bits - alpha, u, v, MM counts, criterions - in every lane layout (16, 32 and
+    64 lanes per row) and with two batches per call."""
+    from tclip_amd import engine, synth
+    B = 2
+    iters, iter_mm = (3, 151) if K >= 397 else (4, 230)
+    x_q, _ = synth.make_query_tasks(B * N, K, seed=8100 + K, k_eff=(min(4, K) if few else None))
+    x_s = y_s = None
+    if few:
+        x_s, y_s = synth.make_support(B * N, K, 1, seed=8200 + K)
+        x_s, y_s = x_s.to(DEV), y_s.squeeze(2).to(DEV)
+    kw = dict(n_batches=B, iters=iters, iter_mm=iter_mm, lambd=max(1, int(K / 5)) * 75, hard=hard)
+    res = {}
+    try:
+        for mode in (0, 1, -1):
+            _set_split(mode)
+            res[mode] = engine.run_em_dirichlet(x_q.to(DEV), x_s, y_s, **kw)
+            torch.cuda.synchronize()
+    finally:
+        _set_split(-1)
+    for mode in (1, -1):
+        for name in ("alpha", "u", "v", "preds", "mm_iters", "criterions"):
+            assert torch.equal(getattr(res[mode], name), getattr(res[0], name)), (mode, name)
+    assert torch.isfinite(res[0].alpha).all()
+
+
+def test_class_split_kernel_with_nan_and_stopped_batches():
+    """A NaN feature (the block-uniform generic path inside k_mm_split) and a batch that stops early while the other keeps
+    iterating (rows of a stopped batch are skipped by the same blocks): identical to k_mm_live."""
+    from tclip_amd import engine, synth
+    K, N, B = 40, 4, 2
+    x_q, _ = synth.make_query_tasks(B * N, K, seed=8300)
+    x_bad = x_q.clone()
+    x_bad[1, 3, 5] = float("nan")
+    kw = dict(n_batches=B, iters=4, iter_mm=1000, lambd=int(K / 5) * 75, hard=False)
+    out = {}
+    try:
+        for mode in (0, 1):
+            _set_split(mode)
+            out[mode] = (engine.run_em_dirichlet(x_q.to(DEV), **kw), engine.run_em_dirichlet(x_bad.to(DEV), **kw))
+            torch.cuda.synchronize()
+    finally:
+        _set_split(-1)
+    for a, b in zip(out[0], out[1]):
+        for name in ("alpha", "u", "v", "preds", "mm_iters"):
+            x, y = getattr(a, name), getattr(b, name)
+            assert torch.equal(torch.nan_to_num(x.float(), nan=-7.0), torch.nan_to_num(y.float(), nan=-7.0)), name

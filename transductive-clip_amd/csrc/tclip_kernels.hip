@@ -891,6 +891,310 @@ __global__ __launch_bounds__(64 * W, (E > 16 ? TCLIP_MM_WAVES_LARGE : TCLIP_MM_W
     }
 }
 
+// ------------------------------------------------------------------------------------------
+// Class-split MM iteration (live rows, every outer iteration but the first).
+// Once the first E-step has run, most parameters of a live row have left the neighbourhood of 1 (measured on the
+// reference's alpha at K = 1000: 73 % have a+1 >= 10, 19 % lie in [2.3, 10), 8 % below 2.3; K = 100: 51 / 11 / 38 %).
+// k_mm_live nevertheless runs every element through the nine masked steps of digamma's recurrence (no step needed from
+// 10 on) and through the small-argument lgamma (only used below 2.3): a quarter and a fifth of its phase C.  Here an
+// element executes only what its value class needs.  Per iteration every wavefront sorts its elements into three
+// dense queues in LDS,
+//     A: a+1 < 2.3        recurrence + Sleef's polynomial lgamma
+//     B: 2.3 <= a+1 < 10  recurrence + Sleef's large-argument lgamma
+//     C: a+1 >= 10        large-argument lgamma without the argument shift (a+1 > 7)
+// laid out [A | B | C] in the wavefront's slice (two words per entry: the argument, replaced by lgamma(a+1), and the
+// recurrence's partial sum); the block evaluates the queues in dense 64-entry passes (class A: 128, two entries per
+// lane on the packed pipe), and phase C picks the two words up and runs what is left for every class: where the
+// recurrence leaves x (closed form, digamma_rec_x), digamma's series and the update algebra.
+// The same functions are applied to the same arguments as in k_mm_live, so the results are identical bit for bit
+// (tests/test_gpu_round3.py::test_class_split_kernel_is_invisible).  The host uses it from the second outer
+// iteration on; in the first one every parameter starts at 1 (class A) and the queue traffic would be pure overhead.
+#ifndef TCLIP_SPLIT_FROM
+#define TCLIP_SPLIT_FROM 1         // first outer iteration (0-based) that runs k_mm_split
+#endif
+#ifndef TCLIP_SPLIT_MAX_E
+#define TCLIP_SPLIT_MAX_E 16       // two words of LDS per element: 32 KB per 4-wavefront block at 16 registers per lane
+#endif
+struct SplitCtl { int count[2][3][8]; int bad; float rowsum[2][64]; float psi[2][64]; };
+
+// Sleef's large-argument lgamma for a dense pass of arguments above 7 (class C: >= 10)
+__device__ __forceinline__ float lgamma_gt7_dense(float v) {
+    bool sure;
+    float r = lgamma_sleef_gt7_f64<true>(v, sure);
+    if (__builtin_expect(__ballot(!sure) != 0ull, 0)) r = sure ? r : lgamma_sleef_ge23<true>(v);
+    return r;
+}
+
+// phase C of the split iteration: entry `slot` of the wavefront's slice holds {lgamma(a+1), partial sum of the recurrence}
+template <int E, int G>
+__device__ __forceinline__ void split_apply_updates(float (&beta)[E], const RowY<E, G>& yv, int K, int lane, float psi_s,
+                                                    const LogTabEntry* tab, const float* my0, const float* my1,
+                                                    const uint32_t (&slot)[(E + 1) / 2], bool measure, double& num, double& den) {
+    const int n_full = full_registers<E, G>(K);
+    auto finish = [&](int p, const PkUpdateStage& st) {
+        const int e = 2 * p;
+        const f2 a{beta[e], beta[e + 1]};
+        const f2 nb = pk_mm_update_stage2(st);
+        const bool full = e + 1 < n_full;
+        const bool ok0 = full || elem_of<E, G>(e, lane) < K, ok1 = full || elem_of<E, G>(e + 1, lane) < K;
+        if (measure) {
+            const double d0 = (double)nb.x - (double)a.x, d1 = (double)nb.y - (double)a.y;
+            if (ok0) { num += d0 * d0; den += (double)a.x * (double)a.x; }
+            if (ok1) { num += d1 * d1; den += (double)a.y * (double)a.y; }
+        }
+        if (full) {
+            beta[e] = nb.x;
+            beta[e + 1] = nb.y;
+        } else {
+            beta[e] = ok0 ? nb.x : 0.0f;
+            beta[e + 1] = ok1 ? nb.y : 0.0f;
+        }
+    };
+    PkUpdateStage pending;
+#pragma unroll
+    for (int p = 0; p < E / 2; p++) {
+        const int e = 2 * p;
+        const f2 a{beta[e], beta[e + 1]};
+        const int i0 = (int)(slot[p] & 0xffffu), i1 = (int)(slot[p] >> 16);
+        const f2 lg{my0[i0], my0[i1]}, acc{my1[i0], my1[i1]};
+        const f2 x1 = a + pk(1.0f);
+        const f2 psi1 = pk_digamma_after_rec(pk_digamma_rec_x(x1), acc, tab);
+        const PkUpdateStage st = pk_mm_update_stage1_given(a, f2{yv.get(e), yv.get(e + 1)}, pk(psi_s), psi1, lg);
+        if (p > 0) finish(p - 1, pending);
+        pending = st;
+    }
+    if (E / 2 > 0) finish(E / 2 - 1, pending);
+    if (E & 1) {
+        constexpr int e = E - 1;
+        const float a = beta[e];
+        const int i = (int)(slot[e >> 1] & 0xffffu);
+        const float lg = my0[i], acc = my1[i];
+        const float x1 = a + 1.0f;
+        const float psi1 = digamma_after_rec(digamma_rec_x(x1), acc, tab);
+        const float nb = mm_update_algebra(a, yv.get(e), psi_s, psi1, lg);
+        const bool ok = elem_of<E, G>(e, lane) < K;
+        if (measure && ok) {
+            const double df = (double)nb - (double)a;
+            num += df * df;
+            den += (double)a * (double)a;
+        }
+        beta[e] = ok ? nb : 0.0f;
+    }
+}
+
+template <int E, int W, int G>
+__device__ __forceinline__ void mm_iterate_block_split(float (&beta)[E], const RowY<E, G>& yv, int K, int lane, bool active,
+                                                       const LogTabEntry* tab, float* plane0, float* plane1, SplitCtl* ctl,
+                                                       int turn, bool measure, double& num, double& den) {
+    constexpr int kSlice = 64 * E;                                // entries of a wavefront's slice
+    const int wave = threadIdx.x >> 6, lane64 = threadIdx.x & 63;
+    float* my0 = plane0 + wave * kSlice;
+    float* my1 = plane1 + wave * kSlice;
+    float s = 16.0f;
+    bool in_domain = true;
+    if (active) {
+        s = row_sum_torch<E, G>(beta, K, lane);
+        in_domain = lane != 0 || (fast_range_f32(s) && s <= 0x1p40f);     // the sum lives in lane 0
+#pragma unroll
+        for (int e = 0; e < E; e++) in_domain = in_domain && mm_fast_domain(beta[e]);
+    }
+    if (lane == 0) ctl->rowsum[turn & 1][threadIdx.x / G] = s;
+    // phase A, first sweep: the sizes of this wavefront's three classes (one v_cmp per threshold writes the 64-lane mask,
+    // the counting runs on the scalar unit).  Only the last registers of a lane can hold slots beyond the row (the
+    // kernel is instantiated for the smallest E that covers K: at most three registers of slack, the fourth for the
+    // upper half of the 64-lane layout); their slots are masked out of the queues, all other registers are queued whole.
+    // (Lane groups without a row hold zeros and travel as class A; they only occur in the last block of a list.)
+    constexpr int kFirstRagged = E > 4 ? E - 4 : 0;
+    int nA = 0, nC = 0, nV = kFirstRagged * 64;
+#pragma unroll
+    for (int e = 0; e < E; e++) {
+        const float x1 = beta[e] + 1.0f;
+        unsigned long long mA = __builtin_amdgcn_ballot_w64(x1 < 2.3f), mC = __builtin_amdgcn_ballot_w64(x1 >= 10.0f);
+        if (e >= kFirstRagged) {
+            const unsigned long long mv = __builtin_amdgcn_ballot_w64(elem_of<E, G>(e, lane) < K);
+            mA &= mv;
+            mC &= mv;
+            nV += __popcll(mv);
+        }
+        nA += __popcll(mA);
+        nC += __popcll(mC);
+    }
+    const int nB = nV - nA - nC;                                    // NaN compares false twice: class B, in both sweeps
+    // second sweep: every element's argument to its place in [A | B | C]; the place is kept (16 bits) for the pick-up.
+    // The compares are repeated on purpose (the asm keeps the compiler from holding 2 E masks in scalar registers).
+    int cA = 0, cB = nA, cC = nA + nB;
+    uint32_t slot[(E + 1) / 2];
+#pragma unroll
+    for (int e = 0; e < E; e++) {
+        float x1 = beta[e] + 1.0f;
+        asm volatile("" : "+v"(x1));
+        const bool lt = x1 < 2.3f, ge = x1 >= 10.0f;
+        unsigned long long mA = __builtin_amdgcn_ballot_w64(lt), mC = __builtin_amdgcn_ballot_w64(ge);
+        unsigned long long mB = ~(mA | mC);
+        bool in_row = true;
+        if (e >= kFirstRagged) {
+            in_row = elem_of<E, G>(e, lane) < K;
+            const unsigned long long mv = __builtin_amdgcn_ballot_w64(in_row);
+            mA &= mv;
+            mC &= mv;
+            mB &= mv;
+        }
+        // rank + running base in the two v_mbcnt of each class (their addend operand carries the base)
+        const int iA = (int)__builtin_amdgcn_mbcnt_hi((unsigned)(mA >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)mA, (unsigned)cA));
+        const int iB = (int)__builtin_amdgcn_mbcnt_hi((unsigned)(mB >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)mB, (unsigned)cB));
+        const int iC = (int)__builtin_amdgcn_mbcnt_hi((unsigned)(mC >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)mC, (unsigned)cC));
+        int idx = lt ? iA : iB;
+        idx = ge ? iC : idx;
+        if (e >= kFirstRagged) {
+            idx = in_row ? idx : 0;                                 // a slot beyond the row reads entry 0; its result is discarded
+            if (in_row) my0[idx] = x1;
+        } else {
+            my0[idx] = x1;
+        }
+        if (e & 1) slot[e >> 1] |= (uint32_t)idx << 16;
+        else slot[e >> 1] = (uint32_t)idx;
+        cA += __popcll(mA);
+        cB += __popcll(mB);
+        cC += __popcll(mC);
+    }
+    const bool wave_ok = __all(in_domain);
+    if (lane64 == 0) {
+        ctl->count[turn & 1][0][wave] = nA;
+        ctl->count[turn & 1][1][wave] = nB;
+        ctl->count[turn & 1][2][wave] = nC;
+        if (!wave_ok) ctl->bad = 1;
+    }
+    __syncthreads();
+    if (__builtin_expect(ctl->bad != 0, 0)) {                     // NaN / inf / out of range somewhere in the block
+        __syncthreads();
+        if (threadIdx.x == 0) ctl->bad = 0;
+        if (active) {
+            const float psi_s = digamma_f32(ctl->rowsum[turn & 1][threadIdx.x / G]);
+#pragma unroll
+            for (int e = 0; e < E; e++) {
+                const float nb = mm_update_generic(beta[e], yv.get(e), psi_s);
+                const bool ok = elem_of<E, G>(e, lane) < K;
+                if (measure && ok) {
+                    const double df = (double)nb - (double)beta[e];
+                    num += df * df;
+                    den += (double)beta[e] * (double)beta[e];
+                }
+                beta[e] = ok ? nb : 0.0f;
+            }
+        }
+        __syncthreads();
+        return;
+    }
+    // phase B: the block's queues in dense passes.  before[c][w]: class-c entries of the wavefronts in front of w;
+    // off[c][w]: what turns the block-wide index j of a class-c entry of wavefront w into its index in the planes.
+    int before[3][W + 1], off[3][W];
+#pragma unroll
+    for (int c = 0; c < 3; c++) before[c][0] = 0;
+#pragma unroll
+    for (int w = 0; w < W; w++) {
+        int cnt[3];
+#pragma unroll
+        for (int c = 0; c < 3; c++) cnt[c] = __builtin_amdgcn_readfirstlane(ctl->count[turn & 1][c][w]);
+        const int base[3] = {0, cnt[0], cnt[0] + cnt[1]};
+#pragma unroll
+        for (int c = 0; c < 3; c++) {
+            before[c][w + 1] = before[c][w] + cnt[c];
+            off[c][w] = w * kSlice + base[c] - before[c][w];
+        }
+    }
+    const int TA = before[0][W], TB = before[1][W], TC = before[2][W];
+    const int PA = (TA + 127) >> 7, PB = (TB + 63) >> 6, PC = (TC + 63) >> 6;
+    auto locate = [&](const int (&bf)[W + 1], const int (&of)[W], int j) {
+        int o = of[0];
+#pragma unroll
+        for (int w = 1; w < W; w++) o = j >= bf[w] ? of[w] : o;
+        return j + o;
+    };
+    for (int p = (wave + turn) % W; p < PA + PB + PC; p += W) {   // passes dealt to the wavefronts in a rotating order
+        if (p < PA) {
+            const int j0 = p * 128 + lane64, j1 = j0 + 64;
+            const bool ok0 = j0 < TA, ok1 = j1 < TA;
+            const int i0 = locate(before[0], off[0], ok0 ? j0 : 0), i1 = locate(before[0], off[0], ok1 ? j1 : 0);
+            const f2 x{ok0 ? plane0[i0] : 1.5f, ok1 ? plane0[i1] : 1.5f};
+            const f2 acc = pk_digamma_rec_acc(x);
+            const f2 lg = pk_lgamma_sleef_1_23(x);
+            if (ok0) { plane0[i0] = lg.x; plane1[i0] = acc.x; }
+            if (ok1) { plane0[i1] = lg.y; plane1[i1] = acc.y; }
+        } else if (p < PA + PB) {
+            const int j = (p - PA) * 64 + lane64;
+            const bool ok = j < TB;
+            const int i = locate(before[1], off[1], ok ? j : 0);
+            const float x = ok ? plane0[i] : 5.0f;
+            const float acc = digamma_rec_acc(x);
+            const float lg = lgamma_big_dense(x);
+            if (ok) { plane0[i] = lg; plane1[i] = acc; }
+        } else {
+            const int j = (p - PA - PB) * 64 + lane64;
+            const bool ok = j < TC;
+            const int i = locate(before[2], off[2], ok ? j : 0);
+            const float x = ok ? plane0[i] : 16.0f;
+            const float lg = lgamma_gt7_dense(x);
+            if (ok) { plane0[i] = lg; plane1[i] = 0.0f; }
+        }
+    }
+    // digamma of the block's row sums: one lane per row
+    constexpr int kGroups = (64 / G) * W;
+    if (wave == (W - (turn % W) + 1) % W && lane64 < kGroups)
+        ctl->psi[turn & 1][lane64] = digamma_pos_f32(ctl->rowsum[turn & 1][lane64], tab);
+    __syncthreads();
+    // phase C
+    split_apply_updates<E, G>(beta, yv, K, lane, ctl->psi[turn & 1][threadIdx.x / G], tab, my0, my1, slot, measure, num, den);
+}
+
+template <int E, int W, int G>
+__global__ __launch_bounds__(64 * W, TCLIP_MM_WAVES_SMALL) void k_mm_split(MMArgs a) {
+    static_assert(E <= TCLIP_SPLIT_MAX_E, "LDS: two words per element");
+    __shared__ LogTabEntry tab[16];
+    __shared__ float plane0[64 * W * E];
+    __shared__ float plane1[64 * W * E];
+    __shared__ SplitCtl ctl;
+    if (threadIdx.x == 0) ctl.bad = 0;
+    load_log_table(tab);
+    const int lane = threadIdx.x & (G - 1);
+    const int group = threadIdx.x / G;
+    constexpr int kRows = (64 / G) * W;
+    int turn = 0;
+    const int n = *a.n_rows;
+    const int K = a.K;
+    for (int first = blockIdx.x * kRows; first < n; first += gridDim.x * kRows) {   // block-uniform trip count
+        const int i = first + group;
+        const int row = i < n ? a.rows[i] : 0;
+        const bool active = i < n && !a.stop[row / a.rows_per_batch];
+        if (!__syncthreads_or(active)) continue;
+        float beta[E];
+        RowY<E, G> yv;
+        double num = 0.0, den = 0.0;
+        yv.load(a.y + (size_t)row * K, lane, K);
+#pragma unroll
+        for (int e = 0; e < E; e++) {
+            const int d = elem_of<E, G>(e, lane);
+            beta[e] = (active && d < K) ? a.alpha[(size_t)row * K + d] : 0.0f;
+        }
+        for (int l = a.l0; l <= a.l1; l++)
+            mm_iterate_block_split<E, W, G>(beta, yv, K, lane, active, tab, plane0, plane1, &ctl, turn++, a.has_check && l == a.l1, num, den);
+        if (!active) continue;
+#pragma unroll
+        for (int e = 0; e < E; e++) {
+            const int d = elem_of<E, G>(e, lane);
+            if (d < K) a.alpha[(size_t)row * K + d] = beta[e];
+        }
+        if (a.work_counter && lane == 0)
+            atomicAdd(a.work_counter, (unsigned long long)K * (unsigned long long)(a.l1 - a.l0 + 1));
+        if (a.has_check) {
+            const double sn = group_sum_f64_g<G>(num), sd = group_sum_f64_g<G>(den);
+            if (lane == 0) {
+                a.rowpart[2 * (size_t)row] = sn;
+                a.rowpart[2 * (size_t)row + 1] = sd;
+            }
+        }
+    }
+}
+
 // Batch-global stop test (em_dirichlet.py:169-175), one block per batch:
 //   crit = ||b'-b||_F^2 / ||b||_F^2 over all N*K*K entries of the batch;  stop if < 1e-11.
 // fp64 accumulation in a fixed order; the final arithmetic follows the reference's fp32 form
@@ -1722,12 +2026,29 @@ __global__ void k_selftest(unsigned long long* out) {
         const float fast = lgamma_sleef_1_23_f64(x, sure);
         b3 += sure && f32_bits(fast) != f32_bits(lgamma_sleef_05_23(x));
     }
-    // the fp64 form of the large-argument lgamma on every float of [2.3, 2^41]
+    // the fp64 form of the large-argument lgamma on every float of [2.3, 2^41]; above 7 also its no-shift specialisation
     for (uint32_t b = f32_bits(2.3f) + tid; b <= f32_bits(0x1p41f); b += nth) {
         const float x = bits_f32(b);
         bool sure;
         const float fast = lgamma_sleef_ge23_f64<true>(x, sure);
         b3 += sure && f32_bits(fast) != f32_bits(lgamma_sleef_ge23<true>(x));
+        if (x > 7.0f) {
+            bool sure7;
+            const float fast7 = lgamma_sleef_gt7_f64<true>(x, sure7);
+            b3 += f32_bits(fast7) != f32_bits(fast) || sure7 != sure;
+        }
+    }
+    // (2, continued) digamma in the pieces the class-split kernel uses, on every float of [1, 16): the closed form of where
+    // the recurrence leaves x against the loop, the packed forms against the scalar ones, the whole against digamma_xp1
+    for (uint32_t b = f32_bits(1.0f) + tid; b < f32_bits(16.0f); b += nth) {
+        const float x1 = bits_f32(b);
+        const float xc = digamma_rec_x(x1), acc = digamma_rec_acc(x1);
+        b2 += f32_bits(xc) != f32_bits(digamma_rec_x_loop(x1));
+        b2 += f32_bits(digamma_after_rec(xc, acc, tab)) != f32_bits(digamma_pos_f32(x1, tab));
+        const f2 xp{x1, bits_f32(b ^ 0x00400000u)};           // a second argument from the other half of the binade
+        const f2 xcp = pk_digamma_rec_x(xp), accp = pk_digamma_rec_acc(xp), psip = pk_digamma_after_rec(xcp, accp, tab);
+        b2 += f32_bits(xcp.x) != f32_bits(xc) || f32_bits(accp.x) != f32_bits(acc);
+        b2 += f32_bits(psip.x) != f32_bits(digamma_pos_f32(xp.x, tab)) || f32_bits(psip.y) != f32_bits(digamma_pos_f32(xp.y, tab));
     }
     atomicAdd(&out[0], b0); atomicAdd(&out[1], b1); atomicAdd(&out[2], b2);
     atomicAdd(&out[3], b3); atomicAdd(&out[4], b4); atomicAdd(&out[5], b5);
@@ -1766,6 +2087,7 @@ struct Profile {
 thread_local Profile g_prof;
 static int g_probe_chunks = TCLIP_PROBE_CHUNKS;     // tclip_debug_set_probe_chunks
 static int g_rowset_min_rows = -1;                  // tclip_debug_set_rowset_min_rows; negative: the default rule
+static int g_mm_split = -1;                         // tclip_debug_set_mm_split: 0 never, 1 always, negative: from the second outer iteration on
 
 static hipEvent_t prof_event() {
     if (g_prof.used == g_prof.ev.size()) {
@@ -1873,12 +2195,19 @@ static void dispatch_E(int K, Args... args) {
 #ifndef TCLIP_MM_LAUNCH_WAVES
 #define TCLIP_MM_LAUNCH_WAVES 4
 #endif
-enum MMKind { kMMLive = 0, kMMDead = 1, kMMProbe = 2 };
+enum MMKind { kMMLive = 0, kMMDead = 1, kMMProbe = 2, kMMSplit = 3 };
 template <int E, int G>
 static void launch_mm_EG(int dead, int rows, hipStream_t st, const MMArgs& a) {
     constexpr int kWaves = TCLIP_MM_LAUNCH_WAVES, kRowsPerBlock = (64 / G) * kWaves;
     int grid = (rows + kRowsPerBlock - 1) / kRowsPerBlock;
     if (grid > 256 * 16) grid = 256 * 16;
+    if (dead == kMMSplit) {                        // live rows through the class-split kernel where it exists (E <= 16)
+        if constexpr (E <= TCLIP_SPLIT_MAX_E) {
+            hipLaunchKernelGGL((k_mm_split<E, kWaves, G>), dim3(grid), dim3(64 * kWaves), 0, st, a);
+            return;
+        }
+        dead = kMMLive;
+    }
     if (dead == kMMProbe) hipLaunchKernelGGL((k_mm_probe<E, G>), dim3(grid), dim3(256), 0, st, a);
     else if (dead) hipLaunchKernelGGL((k_mm_live<E, kWaves, true, 1, G>), dim3(grid), dim3(64 * kWaves), 0, st, a);
     else hipLaunchKernelGGL((k_mm_live<E, kWaves, false, 1, G>), dim3(grid), dim3(64 * kWaves), 0, st, a);
@@ -2084,8 +2413,10 @@ static int enqueue_batches(const tclip_problem& p, const float* x_q, const float
             hipEvent_t e0 = g_prof.on ? prof_event() : nullptr, e1 = g_prof.on ? prof_event() : nullptr;
             if (e0 && e1) TCLIP_HIP(hipEventRecord(e0, st));
             a.rows = live_rows; a.n_rows = counts + 1;
-            launch_mm(kMMLive, K, TK, st, a);
-            if (e0 && e1) TCLIP_HIP(hipEventRecord(e1, st));    // the instrumentation covers k_mm_live only
+            // class-split kernel once the parameters have moved away from their start at 1 (k_mm_split)
+            const bool split = g_mm_split < 0 ? it >= TCLIP_SPLIT_FROM : (g_mm_split >= 100 ? it >= g_mm_split - 100 : g_mm_split != 0);
+            launch_mm(split ? kMMSplit : kMMLive, K, TK, st, a);
+            if (e0 && e1) TCLIP_HIP(hipEventRecord(e1, st));    // the instrumentation covers k_mm_live / k_mm_split only
             if (zs && a.has_check) {          // dead rows only matter through their stop-test terms
                 a.rows = dead_list[c & 1]; a.n_rows = dead_counts + c; a.work_counter = nullptr;
                 // the probe needs the row to be ON its cycle already; rows that were still approaching
@@ -2635,6 +2966,11 @@ int tclip_probability_features(const float* visual, const float* text, int64_t n
 
 int tclip_debug_set_rowset_min_rows(int32_t rows) {
     g_rowset_min_rows = rows;
+    return TCLIP_OK;
+}
+
+int tclip_debug_set_mm_split(int32_t mode) {
+    g_mm_split = mode;
     return TCLIP_OK;
 }
 

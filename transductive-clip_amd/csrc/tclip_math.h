@@ -500,14 +500,37 @@ TCLIP_HD double logk2f_f64(float hi, double val) {
     const double x2 = x * x;
     return __builtin_fma((double)e, kLn2Df, __builtin_fma(x2 * x, (double)t, x + x));
 }
+// logk2f_f64 for an argument in [1, 1.25): the exponent split is 2^0 (hi * 4/3 lies in [1.33, 1.67)), and - for the one
+// caller, the Stirling correction 1 + u t <= 1.012 of an argument above 7, whose logarithm is at most 1e-3 of the
+// lgamma value it is added to - the quotient needs ~30 good bits, which one Newton step on the fp32 reciprocal gives
+// (the general form polishes the quotient to 2^-52).  The fp32 quantities Sleef's polynomial sees are the same.
+template <bool kFast>
+TCLIP_HD double logk2f_f64_near1(float hi, double val) {
+    const float nx = hi + -1.0f, dnx = hi + 1.0f;
+    const float tq = rcp_ieee<kFast>(dnx);
+    const float xx = nx * tq;
+    const float x2x = xx * xx;
+    float t = 0.2392828464508056640625f;
+    t = __builtin_fmaf(t, x2x, 0.28518211841583251953125f);
+    t = __builtin_fmaf(t, x2x, 0.400005877017974853515625f);
+    t = __builtin_fmaf(t, x2x, 0.666666686534881591796875f);
+    const double N = val - 1.0, D = val + 1.0;
+    double r = (double)tq;
+    r = __builtin_fma(r, __builtin_fma(-D, r, 1.0), r);
+    const double x = N * r;
+    const double x2 = x * x;
+    return __builtin_fma(x2 * x, (double)t, x + x);
+}
 TCLIP_HD uint32_t f64_distance_from_f32_midpoint(double v) {
     const uint32_t below = (uint32_t)f64_bits(v) & 0x1fffffffu;
     return below >= 0x10000000u ? below - 0x10000000u : 0x10000000u - below;
 }
 // pd: the shift product (1 beyond 7), v: the value whose RN32 is returned
-template <bool kFast>
+// kGt7: the caller guarantees a > 7 (no shift: product 1, the quotient is corr itself) - the same operations minus the
+// ones that multiply or divide by 1.0
+template <bool kFast, bool kGt7 = false>
 TCLIP_HD float lgamma_sleef_ge23_f64_core(float a, double& pd, double& v) {
-    const bool o = a <= 7.0f;
+    const bool o = kGt7 ? false : a <= 7.0f;
     const double ad = (double)a;
     // shift product a (a+1) (a+2): its hi word is RN32 of a double-float that holds the product to ~2^-45
     pd = o ? (ad * (ad + 1.0)) * (ad + 2.0) : 1.0;
@@ -530,6 +553,10 @@ TCLIP_HD float lgamma_sleef_ge23_f64_core(float a, double& pd, double& v) {
     // corr = 1 + u t (u t is exact in fp64), divided by the shift product
     const float ch = u * t + 1.0f;                                 // hi word of corr
     const double cd = __builtin_fma((double)u, (double)t, 1.0);
+    if (kGt7) {                                                    // prod = 1: tp = 1, qh = ch * 1, rp = 1, qd = cd exactly
+        v = c + logk2f_f64_near1<kFast>(ch, cd);
+        return (float)v;
+    }
     const float tp = rcp_ieee<kFast>(ph);
     const float qh = ch * tp;                                      // hi word of corr / prod as df_div forms it
     double rp = (double)tp;
@@ -538,6 +565,13 @@ TCLIP_HD float lgamma_sleef_ge23_f64_core(float a, double& pd, double& v) {
     qd = __builtin_fma(__builtin_fma(-pd, qd, cd), rp, qd);
     v = c + logk2f_f64<kFast>(qh, qd);
     return (float)v;
+}
+template <bool kFast>
+TCLIP_HD float lgamma_sleef_gt7_f64(float a, bool& sure) {        // a > 7
+    double pd, v;
+    const float r = lgamma_sleef_ge23_f64_core<kFast, true>(a, pd, v);
+    sure = f64_rounds_surely_to_f32(v, kGe23WindowLog2);
+    return r;
 }
 template <bool kFast>
 TCLIP_HD float lgamma_sleef_ge23_f64(float a, bool& sure) {
@@ -680,6 +714,50 @@ TCLIP_HD float digamma_xp1(float a, const LogTabEntry* tab) {
         x += m;
     }
     const float series = digamma_series<true>(x, acc, tab);  // x <= 2^40 + 9 < 1e17
+    return (x == 10.0f) ? acc + 2.25175258906672110764f : series;
+}
+
+// digamma_xp1 in two pieces, for callers that evaluate the recurrence elsewhere than the series (the class-split MM
+// kernel runs it on a dense queue of the arguments below 10 only):
+//   digamma_rec_acc(x1)   the partial sum the loop `while (x < 10) {acc -= 1/x; x += 1}` leaves, started at x = x1 >= 1;
+//   digamma_rec_x(x1)     the x it leaves, in closed form;
+//   digamma_after_rec     the rest of calc_digamma from those two.
+// Closed form of x: every x += 1 that crosses into a higher binade rounds the sum to that binade's spacing (2^-22 in
+// [2,4), 2^-21 in [4,8), 2^-20 in [8,16)); the integer part does not take part in the rounding, ties-to-even included
+// (an integer is an even multiple of every spacing involved), so the fraction f = x1 - floor(x1) goes through the same
+// three roundings as ((f + 2) + 2) + 4 does, whatever x1's own binade (a rounding to a spacing x1 already has is the
+// identity).  The loop ends on the first x >= 10: 10 exactly when the fraction has rounded to 0 or up to 1, else
+// 10 + fraction.  oracle/mathcheck.cpp::mc_rec_closed_form compares the two on EVERY float of [1, 10).
+TCLIP_HD float digamma_rec_acc(float x1) {
+    float x = x1, acc = 0.0f;
+#if defined(__HIP_DEVICE_COMPILE__)
+#pragma unroll
+#endif
+    for (int j = 0; j < 9; j++) {
+        const float m = below10_f32(x);
+        acc = __builtin_fmaf(-m, rcp_rn_f32(x), acc);
+        x += m;
+    }
+    return acc;
+}
+TCLIP_HD float digamma_rec_x_loop(float x1) {            // the loop itself (reference for the closed form)
+    float x = x1;
+    for (int j = 0; j < 9; j++) x += below10_f32(x);
+    return x;
+}
+TCLIP_HD float digamma_rec_x(float x1) {                 // 1 <= x1 <= 2^41
+    const float f = x1 - __builtin_floorf(x1);
+    const float r8 = ((f + 2.0f) + 2.0f) + 4.0f;         // 8 + the fraction after the three roundings, in [8, 9]
+#if defined(__HIP_DEVICE_COMPILE__)
+    const float up = __builtin_amdgcn_fmed3f(__builtin_fmaf(r8, 0x1p20f, 1.0f - 9.0f * 0x1p20f), 0.0f, 1.0f);   // 1.0f iff r8 == 9
+#else
+    const float up = r8 == 9.0f ? 1.0f : 0.0f;
+#endif
+    const float small_x = (r8 + 2.0f) - up;
+    return x1 < 10.0f ? small_x : x1;
+}
+TCLIP_HD float digamma_after_rec(float x, float acc, const LogTabEntry* tab) {
+    const float series = digamma_series<true>(x, acc, tab);
     return (x == 10.0f) ? acc + 2.25175258906672110764f : series;
 }
 

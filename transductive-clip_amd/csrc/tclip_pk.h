@@ -82,6 +82,42 @@ __device__ __forceinline__ f2 pk_digamma_xp1(f2 a, const LogTabEntry* tab) {
     return pk_sel(x == pk(10.0f), acc + pk(2.25175258906672110764f), series);
 }
 
+// the two pieces of digamma(a+1) the class-split kernel evaluates in phase C (the recurrence's partial sum comes from
+// the dense queue): where the recurrence leaves x (digamma_rec_x) and the rest of calc_digamma (digamma_after_rec)
+__device__ __forceinline__ f2 pk_digamma_rec_acc(f2 x1) {     // digamma_rec_acc
+    f2 x = x1, acc = pk(0.0f);
+#pragma unroll
+    for (int j = 0; j < 9; j++) {
+        const f2 m{below10_f32(x.x), below10_f32(x.y)};
+        const f2 r = pk_rcp_rn(x);
+        acc = pk_fma(-m, r, acc);
+        x = x + m;
+    }
+    return acc;
+}
+__device__ __forceinline__ f2 pk_digamma_rec_x(f2 x1) {
+    const f2 f = x1 - __builtin_elementwise_floor(x1);
+    const f2 r8 = ((f + pk(2.0f)) + pk(2.0f)) + pk(4.0f);
+    const f2 up{__builtin_amdgcn_fmed3f(__builtin_fmaf(r8.x, 0x1p20f, 1.0f - 9.0f * 0x1p20f), 0.0f, 1.0f),
+                __builtin_amdgcn_fmed3f(__builtin_fmaf(r8.y, 0x1p20f, 1.0f - 9.0f * 0x1p20f), 0.0f, 1.0f)};
+    const f2 small_x = (r8 + pk(2.0f)) - up;
+    return pk_sel(x1 < pk(10.0f), small_x, x1);
+}
+__device__ __forceinline__ f2 pk_digamma_after_rec(f2 x, f2 acc, const LogTabEntry* tab) {
+    const f2 z = pk_rcp_rn(x * x);
+    f2 p = pk(8.33333333333333333333E-2f);
+    p = pk_fma(p, z, pk(-2.10927960927960927961E-2f));
+    p = pk_fma(p, z, pk(7.57575757575757575758E-3f));
+    p = pk_fma(p, z, pk(-4.16666666666666666667E-3f));
+    p = pk_fma(p, z, pk(3.96825396825396825397E-3f));
+    p = pk_fma(p, z, pk(-8.33333333333333333333E-3f));
+    p = pk_fma(p, z, pk(8.33333333333333333333E-2f));
+    const f2 y = z * p;
+    const f2 lg = pk_logf_glibc_ne1(x, tab);
+    const f2 series = ((acc + lg) - pk(0.5f) * pk_rcp_rn(x)) - y;
+    return pk_sel(x == pk(10.0f), acc + pk(2.25175258906672110764f), series);
+}
+
 // double-float helpers, see the df_* functions
 struct P2 { f2 x, y; };
 __device__ __forceinline__ P2 pk_df_add2_f2_f(P2 a, f2 b) {
@@ -221,6 +257,20 @@ struct PkUpdateStage {
     f2 b, curv, delta;
     uint32_t t0, t1;            // table entries of delta.x, delta.y (loaded, not yet used)
 };
+// stage 1 from psi1 = digamma(a+1) and lg1 = lgamma(a+1)
+__device__ __forceinline__ PkUpdateStage pk_mm_update_stage1_given(f2 a, f2 y, f2 psi_s, f2 psi1, f2 lg1) {
+    const f2 t = (pk(0.0f) - lg1) + psi1 * a;
+    const f2 bigv = __builtin_elementwise_abs(pk_div_rn(pk(2.0f) * t, a * a));
+    PkUpdateStage st;
+    st.curv = pk_sel(a > pk(1e-11f), bigv, pk(1.6449340668482264f));
+    f2 b = (psi1 - psi_s) - st.curv * a;
+    st.b = b - y;
+    st.delta = st.b * st.b + pk(4.0f) * st.curv;
+    const uint32_t b0 = f32_bits(st.delta.x), b1 = f32_bits(st.delta.y);
+    st.t0 = kRsqrt14Tab[((((b0 >> 23) - 127u) & 1u) << 15) | ((b0 & 0x7fffffu) >> 8)];
+    st.t1 = kRsqrt14Tab[((((b1 >> 23) - 127u) & 1u) << 15) | ((b1 & 0x7fffffu) >> 8)];
+    return st;
+}
 __device__ __forceinline__ PkUpdateStage pk_mm_update_stage1(f2 a, f2 y, f2 psi_s, f2 lg_big, const LogTabEntry* tab) {
     const f2 x1 = a + pk(1.0f);
     const i2 big = x1 >= pk(2.3f);

@@ -51,6 +51,7 @@ _SIGNATURES = {
     "tclip_profile_enable": (ctypes.c_int, [ctypes.c_int]),
     "tclip_debug_set_probe_chunks": (ctypes.c_int, [ctypes.c_int32]),
     "tclip_debug_set_rowset_min_rows": (ctypes.c_int, [ctypes.c_int32]),
+    "tclip_debug_set_mm_split": (ctypes.c_int, [ctypes.c_int32]),
     "tclip_profile_collect": (ctypes.c_int, [ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_double),
                                              ctypes.POINTER(ctypes.c_int64), ctypes.POINTER(ctypes.c_int64)]),
 }
@@ -61,9 +62,11 @@ _lib = None
 def lib():
     global _lib
     if _lib is None:
-        if not os.path.exists(LIB_PATH):
+        # TCLIP_LIB: another build of the same library (tuning variants from scripts/build_variant.sh); never a fallback
+        path = os.environ.get("TCLIP_LIB") or LIB_PATH
+        if not os.path.exists(path):
             raise RuntimeError(
-                f"{LIB_PATH} is missing: build it with `python transductive-clip_amd/build.py` "
+                f"{path} is missing: build it with `python transductive-clip_amd/build.py` "
                 "(there is no CPU or PyTorch fallback for the EM-Dirichlet path)")
         # torch must be loaded first: libtclip.so needs libamdhip64.so.7 and has to bind to the ONE
         # HIP runtime of the process, the copy bundled with torch (same SONAME).  Loaded the other
@@ -73,7 +76,7 @@ def lib():
         hip_rt = os.path.join(os.path.dirname(torch.__file__), "lib", "libamdhip64.so")
         if os.path.exists(hip_rt):
             ctypes.CDLL(hip_rt, mode=ctypes.RTLD_GLOBAL)
-        l = ctypes.CDLL(LIB_PATH)
+        l = ctypes.CDLL(path)
         for name, (res, args) in _SIGNATURES.items():
             fn = getattr(l, name)
             fn.restype, fn.argtypes = res, args
