@@ -70,6 +70,7 @@ void mc_rec_closed_form(unsigned long long* out) {
         const float xc = tclip::digamma_rec_x(x1), xl = tclip::digamma_rec_x_loop(x1);
         if (tclip::f32_bits(xc) != tclip::f32_bits(xl)) bad_x++;
         if ((bb & 7) == 0) {            // the functions themselves on every 8th float
+            if (x1 >= 2.3f && tclip::f32_bits(tclip::digamma_rec_acc_ge23(x1)) != tclip::f32_bits(tclip::digamma_rec_acc(x1))) bad_psi++;
             const float whole = tclip::digamma_pos_f32(x1, tclip::kLogTab);
             const float pieces = tclip::digamma_after_rec(xc, tclip::digamma_rec_acc(x1), tclip::kLogTab);
             if (tclip::f32_bits(whole) != tclip::f32_bits(pieces)) bad_psi++;

@@ -26,7 +26,7 @@ for f in sorted(glob.glob(f"{R}/gpurun_out/pmc_{key}.pass*.csv")):
         k = r["Kernel_Name"].split("(")[0].replace("void tclip::", "").replace("tclip::", "")
         agg[k][r["Counter_Name"]] += float(r["Counter_Value"])
         cnt[(k, r["Counter_Name"])].add(r["Dispatch_Id"])
-        if "k_mm_live" in k and "false" in k:
+        if ("k_mm_live" in k and "false" in k) or "k_mm_split" in k:
             extra = {"scratch_bytes_per_lane": int(r.get("Scratch_Size", 0) or 0), "vgpr": int(r.get("VGPR_Count", 0) or 0),
                      "lds_bytes_per_block": int(r.get("LDS_Block_Size", 0) or 0)}
 log = open(f"{R}/gpurun_out/pmc_{key}.pass0.log").read()
@@ -35,9 +35,15 @@ K, B, N, iters, launches, updates = runs[-1]
 K, B, N = int(K), int(B), int(N)
 n_runs = len(runs)
 updates_total = sum(float(r[5]) for r in runs)
-live = max((k for k in agg if "k_mm_live" in k and "false" in k), key=lambda k: agg[k].get("SQ_INSTS_VALU", 0))
-a = agg[live]
-n_disp = len(cnt[(live, "SQ_INSTS_VALU")])
+# the live rows run through k_mm_live<.., false, ..> in the first outer iteration and through k_mm_split afterwards: the
+# summary covers both (the element-update counter does), `per_kernel` keeps them apart
+mm = [k for k in agg if ("k_mm_live" in k and "false" in k) or "k_mm_split" in k]
+live = " + ".join(sorted(mm))
+a = collections.defaultdict(float)
+for k in mm:
+    for c, v in agg[k].items():
+        a[c] += v
+n_disp = sum(len(cnt[(k, "SQ_INSTS_VALU")]) for k in mm)
 copy_disp = len(cnt[("k_copy", "FETCH_SIZE")])
 copy_bytes = 4.0 * B * N * 75 * K * n_runs                       # every run copies x_q -> u once (split over the stream groups)
 fetch_ratio = agg["k_copy"]["FETCH_SIZE"] * 1024 / copy_bytes if copy_bytes else None
@@ -49,6 +55,11 @@ out = {
     "kernel": live, "dispatches": n_disp,
     "lane_instr_per_update": a["SQ_INSTS_VALU"] * 64 / updates_total,
     "valu_wave_instr": a["SQ_INSTS_VALU"], "element_updates": updates_total,
+    "per_kernel": {k: {"dispatches": len(cnt[(k, "SQ_INSTS_VALU")]), "valu_wave_instr": agg[k]["SQ_INSTS_VALU"],
+                       "wave_cycles": agg[k]["SQ_WAVE_CYCLES"], "wait_frac": agg[k]["SQ_WAIT_ANY"] / max(agg[k]["SQ_WAVE_CYCLES"], 1),
+                       "valu_active_quad_cycles": agg[k]["SQ_ACTIVE_INST_VALU"], "gui_active": agg[k]["GRBM_GUI_ACTIVE"],
+                       "valu_busy_frac": agg[k]["SQ_ACTIVE_INST_VALU"] * 4 / max(agg[k]["GRBM_GUI_ACTIVE"] / 8 * 1024, 1)} for k in mm},
+    "valu_busy_frac": a["SQ_ACTIVE_INST_VALU"] * 4 / max(a["GRBM_GUI_ACTIVE"] / 8 * 1024, 1),
     "wait_frac": a["SQ_WAIT_ANY"] / a["SQ_WAVE_CYCLES"], "issue_stall_frac": a["SQ_WAIT_INST_ANY"] / a["SQ_WAVE_CYCLES"],
     "active_frac": a["SQ_ACTIVE_INST_ANY"] / a["SQ_WAVE_CYCLES"],
     "trans_frac_of_valu": a["SQ_INSTS_VALU_TRANS_F32"] / a["SQ_INSTS_VALU"],

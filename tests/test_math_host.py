@@ -126,3 +126,29 @@ def test_lgamma_fp64_form_agrees_on_every_float_of_2p3_to_2e41(mc):
     assert differ == 0, "a 'sure' argument rounds differently in the fp64 form"
     assert 0 < unsure < visited // 10000
     assert needed_window <= 1 << 10, needed_window             # the window in use is 2^13
+
+
+def test_no_shift_lgamma_form_agrees_on_every_float_above_7(mc):
+    """class C of the split MM kernel (alpha + 1 >= 10) evaluates Sleef's large-argument lgamma without the argument shift
+    and with a 30-bit logarithm of the Stirling correction (lgamma_sleef_gt7_f64): against the double-float restatement
+    on EVERY float of (7, 2^41]"""
+    import struct
+    bits = lambda v: struct.unpack("<I", struct.pack("<f", v))[0]
+    out = (ctypes.c_ulonglong * 4)()
+    mc.mc_lgamma_gt7_f64_form(ctypes.c_uint(bits(7.0) + 1), ctypes.c_uint(bits(2.0 ** 41) + 1), ctypes.c_uint(1), out)
+    differ, unsure, visited, needed_window = list(out)
+    assert visited == bits(2.0 ** 41) - bits(7.0)
+    assert differ == 0, "a 'sure' argument rounds differently in the no-shift form"
+    assert 0 < unsure < visited // 10000
+    assert needed_window <= 1 << 8, needed_window              # measured 37; the window in use is 2^13
+
+
+def test_digamma_recurrence_pieces_on_every_float_of_1_to_24(mc):
+    """the split MM kernel evaluates digamma(alpha + 1) in pieces: the recurrence's partial sum on a dense queue, where the
+    recurrence leaves x in closed form (digamma_rec_x), the series afterwards.  The closed form against the loop on EVERY
+    float of [1, 24); the recomposed digamma and the class-wise recurrences on every eighth."""
+    out = (ctypes.c_ulonglong * 4)()
+    mc.mc_rec_closed_form(out)
+    bad_x, bad_psi, bad_lg, visited = list(out)
+    assert visited == 37748736
+    assert bad_x == 0 and bad_psi == 0 and bad_lg == 0

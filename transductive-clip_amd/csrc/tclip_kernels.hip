@@ -893,29 +893,30 @@ __global__ __launch_bounds__(64 * W, (E > 16 ? TCLIP_MM_WAVES_LARGE : TCLIP_MM_W
 
 // ------------------------------------------------------------------------------------------
 // Class-split MM iteration (live rows, every outer iteration but the first).
-// Once the first E-step has run, most parameters of a live row have left the neighbourhood of 1 (measured on the
-// reference's alpha at K = 1000: 73 % have a+1 >= 10, 19 % lie in [2.3, 10), 8 % below 2.3; K = 100: 51 / 11 / 38 %).
-// k_mm_live nevertheless runs every element through the nine masked steps of digamma's recurrence (no step needed from
-// 10 on) and through the small-argument lgamma (only used below 2.3): a quarter and a fifth of its phase C.  Here an
-// element executes only what its value class needs.  Per iteration every wavefront sorts its elements into three
-// dense queues in LDS,
-//     A: a+1 < 2.3        recurrence + Sleef's polynomial lgamma
-//     B: 2.3 <= a+1 < 10  recurrence + Sleef's large-argument lgamma
-//     C: a+1 >= 10        large-argument lgamma without the argument shift (a+1 > 7)
-// laid out [A | B | C] in the wavefront's slice (two words per entry: the argument, replaced by lgamma(a+1), and the
-// recurrence's partial sum); the block evaluates the queues in dense 64-entry passes (class A: 128, two entries per
-// lane on the packed pipe), and phase C picks the two words up and runs what is left for every class: where the
-// recurrence leaves x (closed form, digamma_rec_x), digamma's series and the update algebra.
-// The same functions are applied to the same arguments as in k_mm_live, so the results are identical bit for bit
-// (tests/test_gpu_round3.py::test_class_split_kernel_is_invisible).  The host uses it from the second outer
-// iteration on; in the first one every parameter starts at 1 (class A) and the queue traffic would be pure overhead.
+// Once the first E-step has run, the parameters of a live row leave the neighbourhood of 1 (measured on the reference's
+// alpha at K = 1000: at the start of outer iteration 2, 45 % have a+1 < 2.3, 25 % lie in [2.3, 10), 29 % are >= 10; after
+// 20 iterations 8 / 19 / 73 %; K = 100: 35 / 12 / 53 %).  k_mm_live nevertheless runs every element through the nine masked
+// steps of digamma's recurrence (no step is taken from 10 on) and through the small-argument lgamma (only used below 2.3):
+// a quarter and a fifth of its phase C.  Here an element executes only what its value class needs.  Per iteration the
+// wavefront sorts its elements into three dense queues in LDS,
+//     A: a+1 < 2.3        recurrence (eight unmasked steps + one) + Sleef's polynomial lgamma, two entries per lane (packed)
+//     B: 2.3 <= a+1 < 10  recurrence (eight masked steps) + Sleef's large-argument lgamma
+//     C: a+1 >= 10        no recurrence; the large-argument lgamma without its argument shift (a+1 > 7)
+// laid out [A | B | C] in two planes of one word per element: the argument, replaced by lgamma(a+1), and digamma(a+1).
+// Dense 64-entry passes (class A: 128) evaluate BOTH special functions of the class; phase C picks the two words up
+// and runs the update algebra.  The same functions are applied to the same arguments as in k_mm_live, so the results are
+// identical bit for bit (tests/test_gpu_round3.py::test_class_split_kernel_is_invisible).
+// One wavefront per block: the queues are private to the wavefront and nothing waits at a barrier for another
+// wavefront's dense passes (measured against four wavefronts sharing block-wide queues: K = 100 380 -> 369 ms,
+// K = 397 453 -> 439 ms, K = 1000 -1 %; k_mm_live, whose single queue is short, is better off sharing).
+// The host uses this kernel from the second outer iteration on; in the first one every parameter starts at 1 (class A)
+// and the queue traffic would be pure overhead (measured: +15 % there).
 #ifndef TCLIP_SPLIT_FROM
 #define TCLIP_SPLIT_FROM 1         // first outer iteration (0-based) that runs k_mm_split
 #endif
 #ifndef TCLIP_SPLIT_MAX_E
-#define TCLIP_SPLIT_MAX_E 16       // two words of LDS per element: 32 KB per 4-wavefront block at 16 registers per lane
+#define TCLIP_SPLIT_MAX_E 16       // two words of LDS per element: 8 KB per wavefront at 16 registers per lane
 #endif
-struct SplitCtl { int count[2][3][8]; int bad; float rowsum[2][64]; float psi[2][64]; };
 
 // Sleef's large-argument lgamma for a dense pass of arguments above 7 (class C: >= 10)
 __device__ __forceinline__ float lgamma_gt7_dense(float v) {
@@ -925,11 +926,11 @@ __device__ __forceinline__ float lgamma_gt7_dense(float v) {
     return r;
 }
 
-// phase C of the split iteration: entry `slot` of the wavefront's slice holds {lgamma(a+1), partial sum of the recurrence}
+// phase C of the split iteration: entry `slot` of the wavefront's planes holds lgamma(a+1) and digamma(a+1)
 template <int E, int G>
 __device__ __forceinline__ void split_apply_updates(float (&beta)[E], const RowY<E, G>& yv, int K, int lane, float psi_s,
-                                                    const LogTabEntry* tab, const float* my0, const float* my1,
-                                                    const uint32_t (&slot)[(E + 1) / 2], bool measure, double& num, double& den) {
+                                                    const float* my0, const float* my1, const uint32_t (&slot)[(E + 1) / 2],
+                                                    bool measure, double& num, double& den) {
     const int n_full = full_registers<E, G>(K);
     auto finish = [&](int p, const PkUpdateStage& st) {
         const int e = 2 * p;
@@ -956,9 +957,7 @@ __device__ __forceinline__ void split_apply_updates(float (&beta)[E], const RowY
         const int e = 2 * p;
         const f2 a{beta[e], beta[e + 1]};
         const int i0 = (int)(slot[p] & 0xffffu), i1 = (int)(slot[p] >> 16);
-        const f2 lg{my0[i0], my0[i1]}, acc{my1[i0], my1[i1]};
-        const f2 x1 = a + pk(1.0f);
-        const f2 psi1 = pk_digamma_after_rec(pk_digamma_rec_x(x1), acc, tab);
+        const f2 lg{my0[i0], my0[i1]}, psi1{my1[i0], my1[i1]};
         const PkUpdateStage st = pk_mm_update_stage1_given(a, f2{yv.get(e), yv.get(e + 1)}, pk(psi_s), psi1, lg);
         if (p > 0) finish(p - 1, pending);
         pending = st;
@@ -968,10 +967,7 @@ __device__ __forceinline__ void split_apply_updates(float (&beta)[E], const RowY
         constexpr int e = E - 1;
         const float a = beta[e];
         const int i = (int)(slot[e >> 1] & 0xffffu);
-        const float lg = my0[i], acc = my1[i];
-        const float x1 = a + 1.0f;
-        const float psi1 = digamma_after_rec(digamma_rec_x(x1), acc, tab);
-        const float nb = mm_update_algebra(a, yv.get(e), psi_s, psi1, lg);
+        const float nb = mm_update_algebra(a, yv.get(e), psi_s, my1[i], my0[i]);
         const bool ok = elem_of<E, G>(e, lane) < K;
         if (measure && ok) {
             const double df = (double)nb - (double)a;
@@ -982,14 +978,12 @@ __device__ __forceinline__ void split_apply_updates(float (&beta)[E], const RowY
     }
 }
 
-template <int E, int W, int G>
-__device__ __forceinline__ void mm_iterate_block_split(float (&beta)[E], const RowY<E, G>& yv, int K, int lane, bool active,
-                                                       const LogTabEntry* tab, float* plane0, float* plane1, SplitCtl* ctl,
-                                                       int turn, bool measure, double& num, double& den) {
-    constexpr int kSlice = 64 * E;                                // entries of a wavefront's slice
-    const int wave = threadIdx.x >> 6, lane64 = threadIdx.x & 63;
-    float* my0 = plane0 + wave * kSlice;
-    float* my1 = plane1 + wave * kSlice;
+// my0 / my1: the wavefront's two planes of 64 E words
+template <int E, int G>
+__device__ __forceinline__ void mm_iterate_wave_split(float (&beta)[E], const RowY<E, G>& yv, int K, int lane, bool active,
+                                                      const LogTabEntry* tab, float* my0, float* my1, bool measure,
+                                                      double& num, double& den) {
+    const int lane64 = threadIdx.x & 63;
     float s = 16.0f;
     bool in_domain = true;
     if (active) {
@@ -998,11 +992,28 @@ __device__ __forceinline__ void mm_iterate_block_split(float (&beta)[E], const R
 #pragma unroll
         for (int e = 0; e < E; e++) in_domain = in_domain && mm_fast_domain(beta[e]);
     }
-    if (lane == 0) ctl->rowsum[turn & 1][threadIdx.x / G] = s;
-    // phase A, first sweep: the sizes of this wavefront's three classes (one v_cmp per threshold writes the 64-lane mask,
-    // the counting runs on the scalar unit).  Only the last registers of a lane can hold slots beyond the row (the
-    // kernel is instantiated for the smallest E that covers K: at most three registers of slack, the fourth for the
-    // upper half of the 64-lane layout); their slots are masked out of the queues, all other registers are queued whole.
+    s = __shfl(s, 0, G);                                            // the row's sum in every lane of its group
+    if (__builtin_expect(!__all(in_domain), 0)) {                   // NaN / inf / out of range somewhere in the wavefront
+        if (active) {
+            const float psi_s = digamma_f32(s);
+#pragma unroll
+            for (int e = 0; e < E; e++) {
+                const float nb = mm_update_generic(beta[e], yv.get(e), psi_s);
+                const bool ok = elem_of<E, G>(e, lane) < K;
+                if (measure && ok) {
+                    const double df = (double)nb - (double)beta[e];
+                    num += df * df;
+                    den += (double)beta[e] * (double)beta[e];
+                }
+                beta[e] = ok ? nb : 0.0f;
+            }
+        }
+        return;
+    }
+    // phase A, first sweep: the sizes of the three classes (one v_cmp per threshold writes the 64-lane mask, the counting
+    // runs on the scalar unit).  Only the last registers of a lane can hold slots beyond the row (the kernel is
+    // instantiated for the smallest E that covers K: at most three registers of slack, the fourth for the upper half of
+    // the 64-lane layout); their slots are masked out of the queues, all other registers are queued whole.
     // (Lane groups without a row hold zeros and travel as class A; they only occur in the last block of a list.)
     constexpr int kFirstRagged = E > 4 ? E - 4 : 0;
     int nA = 0, nC = 0, nV = kFirstRagged * 64;
@@ -1057,115 +1068,70 @@ __device__ __forceinline__ void mm_iterate_block_split(float (&beta)[E], const R
         cB += __popcll(mB);
         cC += __popcll(mC);
     }
-    const bool wave_ok = __all(in_domain);
-    if (lane64 == 0) {
-        ctl->count[turn & 1][0][wave] = nA;
-        ctl->count[turn & 1][1][wave] = nB;
-        ctl->count[turn & 1][2][wave] = nC;
-        if (!wave_ok) ctl->bad = 1;
-    }
-    __syncthreads();
-    if (__builtin_expect(ctl->bad != 0, 0)) {                     // NaN / inf / out of range somewhere in the block
-        __syncthreads();
-        if (threadIdx.x == 0) ctl->bad = 0;
-        if (active) {
-            const float psi_s = digamma_f32(ctl->rowsum[turn & 1][threadIdx.x / G]);
+    const float psi_s = digamma_pos_f32(s, tab);                    // the row sums of the wavefront's rows, one evaluation
+    // phase B: the queues in dense passes; entry i leaves with lgamma(a+1) in plane 0 and digamma(a+1) in plane 1
+    for (int j = 0; j < nA; j += 128) {
+        const int i0 = j + lane64, i1 = i0 + 64;
+        const bool ok0 = i0 < nA, ok1 = i1 < nA;
+        const f2 x{ok0 ? my0[i0] : 1.5f, ok1 ? my0[i1] : 1.5f};
+        f2 xr = x, acc = pk(0.0f);
 #pragma unroll
-            for (int e = 0; e < E; e++) {
-                const float nb = mm_update_generic(beta[e], yv.get(e), psi_s);
-                const bool ok = elem_of<E, G>(e, lane) < K;
-                if (measure && ok) {
-                    const double df = (double)nb - (double)beta[e];
-                    num += df * df;
-                    den += (double)beta[e] * (double)beta[e];
-                }
-                beta[e] = ok ? nb : 0.0f;
-            }
+        for (int k = 0; k < 8; k++) {                               // x + 7 < 10: the first eight steps are always taken
+            acc = acc - pk_rcp_rn(xr);
+            xr = xr + pk(1.0f);
         }
-        __syncthreads();
-        return;
+        const f2 m{below10_f32(xr.x), below10_f32(xr.y)};
+        acc = pk_fma(-m, pk_rcp_rn(xr), acc);
+        xr = xr + m;
+        const f2 psi = pk_digamma_after_rec(xr, acc, tab);
+        const f2 lg = pk_lgamma_sleef_1_23(x);
+        if (ok0) { my0[i0] = lg.x; my1[i0] = psi.x; }
+        if (ok1) { my0[i1] = lg.y; my1[i1] = psi.y; }
     }
-    // phase B: the block's queues in dense passes.  before[c][w]: class-c entries of the wavefronts in front of w;
-    // off[c][w]: what turns the block-wide index j of a class-c entry of wavefront w into its index in the planes.
-    int before[3][W + 1], off[3][W];
+    for (int j = 0; j < nB; j += 64) {
+        const int i = nA + j + lane64;
+        const bool ok = j + lane64 < nB;
+        const float x = ok ? my0[i] : 5.0f;
+        float xr = x, acc = 0.0f;
 #pragma unroll
-    for (int c = 0; c < 3; c++) before[c][0] = 0;
-#pragma unroll
-    for (int w = 0; w < W; w++) {
-        int cnt[3];
-#pragma unroll
-        for (int c = 0; c < 3; c++) cnt[c] = __builtin_amdgcn_readfirstlane(ctl->count[turn & 1][c][w]);
-        const int base[3] = {0, cnt[0], cnt[0] + cnt[1]};
-#pragma unroll
-        for (int c = 0; c < 3; c++) {
-            before[c][w + 1] = before[c][w] + cnt[c];
-            off[c][w] = w * kSlice + base[c] - before[c][w];
+        for (int k = 0; k < 8; k++) {                               // x + 8 >= 10: a ninth step is never taken
+            const float m = below10_f32(xr);
+            acc = __builtin_fmaf(-m, rcp_rn_f32(xr), acc);
+            xr += m;
         }
+        const float psi = digamma_after_rec(xr, acc, tab);
+        const float lg = lgamma_big_dense(x);
+        if (ok) { my0[i] = lg; my1[i] = psi; }
     }
-    const int TA = before[0][W], TB = before[1][W], TC = before[2][W];
-    const int PA = (TA + 127) >> 7, PB = (TB + 63) >> 6, PC = (TC + 63) >> 6;
-    auto locate = [&](const int (&bf)[W + 1], const int (&of)[W], int j) {
-        int o = of[0];
-#pragma unroll
-        for (int w = 1; w < W; w++) o = j >= bf[w] ? of[w] : o;
-        return j + o;
-    };
-    for (int p = (wave + turn) % W; p < PA + PB + PC; p += W) {   // passes dealt to the wavefronts in a rotating order
-        if (p < PA) {
-            const int j0 = p * 128 + lane64, j1 = j0 + 64;
-            const bool ok0 = j0 < TA, ok1 = j1 < TA;
-            const int i0 = locate(before[0], off[0], ok0 ? j0 : 0), i1 = locate(before[0], off[0], ok1 ? j1 : 0);
-            const f2 x{ok0 ? plane0[i0] : 1.5f, ok1 ? plane0[i1] : 1.5f};
-            const f2 acc = pk_digamma_rec_acc(x);
-            const f2 lg = pk_lgamma_sleef_1_23(x);
-            if (ok0) { plane0[i0] = lg.x; plane1[i0] = acc.x; }
-            if (ok1) { plane0[i1] = lg.y; plane1[i1] = acc.y; }
-        } else if (p < PA + PB) {
-            const int j = (p - PA) * 64 + lane64;
-            const bool ok = j < TB;
-            const int i = locate(before[1], off[1], ok ? j : 0);
-            const float x = ok ? plane0[i] : 5.0f;
-            const float acc = digamma_rec_acc(x);
-            const float lg = lgamma_big_dense(x);
-            if (ok) { plane0[i] = lg; plane1[i] = acc; }
-        } else {
-            const int j = (p - PA - PB) * 64 + lane64;
-            const bool ok = j < TC;
-            const int i = locate(before[2], off[2], ok ? j : 0);
-            const float x = ok ? plane0[i] : 16.0f;
-            const float lg = lgamma_gt7_dense(x);
-            if (ok) { plane0[i] = lg; plane1[i] = 0.0f; }
-        }
+    for (int j = 0; j < nC; j += 64) {
+        const int i = nA + nB + j + lane64;
+        const bool ok = j + lane64 < nC;
+        const float x = ok ? my0[i] : 16.0f;
+        const float psi = digamma_after_rec(x, 0.0f, tab);
+        const float lg = lgamma_gt7_dense(x);
+        if (ok) { my0[i] = lg; my1[i] = psi; }
     }
-    // digamma of the block's row sums: one lane per row
-    constexpr int kGroups = (64 / G) * W;
-    if (wave == (W - (turn % W) + 1) % W && lane64 < kGroups)
-        ctl->psi[turn & 1][lane64] = digamma_pos_f32(ctl->rowsum[turn & 1][lane64], tab);
-    __syncthreads();
     // phase C
-    split_apply_updates<E, G>(beta, yv, K, lane, ctl->psi[turn & 1][threadIdx.x / G], tab, my0, my1, slot, measure, num, den);
+    split_apply_updates<E, G>(beta, yv, K, lane, psi_s, my0, my1, slot, measure, num, den);
 }
 
-template <int E, int W, int G>
-__global__ __launch_bounds__(64 * W, TCLIP_MM_WAVES_SMALL) void k_mm_split(MMArgs a) {
+template <int E, int G>
+__global__ __launch_bounds__(64, TCLIP_MM_WAVES_SMALL) void k_mm_split(MMArgs a) {
     static_assert(E <= TCLIP_SPLIT_MAX_E, "LDS: two words per element");
     __shared__ LogTabEntry tab[16];
-    __shared__ float plane0[64 * W * E];
-    __shared__ float plane1[64 * W * E];
-    __shared__ SplitCtl ctl;
-    if (threadIdx.x == 0) ctl.bad = 0;
+    __shared__ float plane0[64 * E];
+    __shared__ float plane1[64 * E];
     load_log_table(tab);
     const int lane = threadIdx.x & (G - 1);
     const int group = threadIdx.x / G;
-    constexpr int kRows = (64 / G) * W;
-    int turn = 0;
+    constexpr int kRows = 64 / G;
     const int n = *a.n_rows;
     const int K = a.K;
-    for (int first = blockIdx.x * kRows; first < n; first += gridDim.x * kRows) {   // block-uniform trip count
+    for (int first = blockIdx.x * kRows; first < n; first += gridDim.x * kRows) {
         const int i = first + group;
         const int row = i < n ? a.rows[i] : 0;
         const bool active = i < n && !a.stop[row / a.rows_per_batch];
-        if (!__syncthreads_or(active)) continue;
+        if (!__any(active)) continue;
         float beta[E];
         RowY<E, G> yv;
         double num = 0.0, den = 0.0;
@@ -1176,7 +1142,7 @@ __global__ __launch_bounds__(64 * W, TCLIP_MM_WAVES_SMALL) void k_mm_split(MMArg
             beta[e] = (active && d < K) ? a.alpha[(size_t)row * K + d] : 0.0f;
         }
         for (int l = a.l0; l <= a.l1; l++)
-            mm_iterate_block_split<E, W, G>(beta, yv, K, lane, active, tab, plane0, plane1, &ctl, turn++, a.has_check && l == a.l1, num, den);
+            mm_iterate_wave_split<E, G>(beta, yv, K, lane, active, tab, plane0, plane1, a.has_check && l == a.l1, num, den);
         if (!active) continue;
 #pragma unroll
         for (int e = 0; e < E; e++) {
@@ -2048,6 +2014,11 @@ __global__ void k_selftest(unsigned long long* out) {
         const f2 xp{x1, bits_f32(b ^ 0x00400000u)};           // a second argument from the other half of the binade
         const f2 xcp = pk_digamma_rec_x(xp), accp = pk_digamma_rec_acc(xp), psip = pk_digamma_after_rec(xcp, accp, tab);
         b2 += f32_bits(xcp.x) != f32_bits(xc) || f32_bits(accp.x) != f32_bits(acc);
+        if (x1 < 2.3f && xp.y < 2.3f) {
+            const f2 a8 = pk_digamma_rec_acc_lt23(xp);
+            b2 += f32_bits(a8.x) != f32_bits(accp.x) || f32_bits(a8.y) != f32_bits(accp.y);
+        }
+        if (x1 >= 2.3f) b2 += f32_bits(digamma_rec_acc_ge23(x1)) != f32_bits(acc);
         b2 += f32_bits(psip.x) != f32_bits(digamma_pos_f32(xp.x, tab)) || f32_bits(psip.y) != f32_bits(digamma_pos_f32(xp.y, tab));
     }
     atomicAdd(&out[0], b0); atomicAdd(&out[1], b1); atomicAdd(&out[2], b2);
@@ -2203,7 +2174,10 @@ static void launch_mm_EG(int dead, int rows, hipStream_t st, const MMArgs& a) {
     if (grid > 256 * 16) grid = 256 * 16;
     if (dead == kMMSplit) {                        // live rows through the class-split kernel where it exists (E <= 16)
         if constexpr (E <= TCLIP_SPLIT_MAX_E) {
-            hipLaunchKernelGGL((k_mm_split<E, kWaves, G>), dim3(grid), dim3(64 * kWaves), 0, st, a);
+            constexpr int kSplitRows = 64 / G;           // one wavefront per block
+            int sgrid = (rows + kSplitRows - 1) / kSplitRows;
+            if (sgrid > 256 * 64) sgrid = 256 * 64;
+            hipLaunchKernelGGL((k_mm_split<E, G>), dim3(sgrid), dim3(64), 0, st, a);
             return;
         }
         dead = kMMLive;

@@ -740,6 +740,18 @@ TCLIP_HD float digamma_rec_acc(float x1) {
     }
     return acc;
 }
+TCLIP_HD float digamma_rec_acc_ge23(float x1) {          // x1 >= 2.3: the ninth step is never taken (x1 + 8 >= 10)
+    float x = x1, acc = 0.0f;
+#if defined(__HIP_DEVICE_COMPILE__)
+#pragma unroll
+#endif
+    for (int j = 0; j < 8; j++) {
+        const float m = below10_f32(x);
+        acc = __builtin_fmaf(-m, rcp_rn_f32(x), acc);
+        x += m;
+    }
+    return acc;
+}
 TCLIP_HD float digamma_rec_x_loop(float x1) {            // the loop itself (reference for the closed form)
     float x = x1;
     for (int j = 0; j < 9; j++) x += below10_f32(x);

@@ -95,6 +95,18 @@ __device__ __forceinline__ f2 pk_digamma_rec_acc(f2 x1) {     // digamma_rec_acc
     }
     return acc;
 }
+// the same for arguments in [1, 2.3) (class A of the split kernel): the first eight steps are always taken (x1 + 7 < 10),
+// only the ninth needs its mask
+__device__ __forceinline__ f2 pk_digamma_rec_acc_lt23(f2 x1) {
+    f2 x = x1, acc = pk(0.0f);
+#pragma unroll
+    for (int j = 0; j < 8; j++) {
+        acc = acc - pk_rcp_rn(x);
+        x = x + pk(1.0f);
+    }
+    const f2 m{below10_f32(x.x), below10_f32(x.y)};
+    return pk_fma(-m, pk_rcp_rn(x), acc);
+}
 __device__ __forceinline__ f2 pk_digamma_rec_x(f2 x1) {
     const f2 f = x1 - __builtin_elementwise_floor(x1);
     const f2 r8 = ((f + pk(2.0f)) + pk(2.0f)) + pk(4.0f);
