@@ -111,12 +111,14 @@ def _set_split(mode):
 
 @pytest.mark.parametrize("K,N,few,hard", [(5, 6, False, False), (10, 8, False, False), (37, 6, False, True), (100, 12, False, False),
                                            (100, 3, True, False), (196, 4, False, False), (256, 3, False, False), (300, 3, False, False),
-                                           (397, 4, False, True), (512, 2, False, False), (1000, 5, False, False), (1024, 2, True, False)])
+                                           (397, 4, False, True), (512, 2, False, False), (620, 2, False, False), (750, 2, False, False),
+                                           (880, 2, False, False), (1000, 5, False, False), (1024, 2, True, False)])
 def test_class_split_kernel_is_invisible(K, N, few, hard):
     """k_mm_split (every element runs only what its value class a+1 < 2.3 / [2.3, 10) / >= 10 needs, through three dense
     LDS queues) against k_mm_live on the same problems: never / from the first outer iteration on / the default rule
     (from the second on) give identical bits - alpha, u, v, MM counts, criterions - in every lane layout (16, 32 and
-    64 lanes per row) and with two batches per call."""
+    64 lanes per row) and with two batches per call.  (Rows shorter than 65 or of 769 .. 896 elements have no split
+    instantiation - too little work per dense pass, too much LDS - and take k_mm_live in every mode.)"""
     from tclip_amd import engine, synth
     B = 2
     iters, iter_mm = (3, 151) if K >= 397 else (4, 230)

@@ -915,7 +915,13 @@ __global__ __launch_bounds__(64 * W, (E > 16 ? TCLIP_MM_WAVES_LARGE : TCLIP_MM_W
 #define TCLIP_SPLIT_FROM 1         // first outer iteration (0-based) that runs k_mm_split
 #endif
 #ifndef TCLIP_SPLIT_MAX_E
-#define TCLIP_SPLIT_MAX_E 16       // two words of LDS per element: 8 KB per wavefront at 16 registers per lane
+#define TCLIP_SPLIT_MAX_E 24       // two words of LDS per element: 8 KB per wavefront at 16 registers per lane (16 wavefronts per CU),
+                                   // 12 KB at 24 (12 wavefronts per CU, which is what those kernels' registers allow anyway)
+#endif
+#ifndef TCLIP_SPLIT_MIN_E
+#define TCLIP_SPLIT_MIN_E 5        // shorter rows fill too little of a dense pass: measured with 16 lanes per row on 1000 tasks,
+                                   // split against k_mm_live: K = 10 +42 %, 37 +6 %, 47 +7 %, 64 +1 %, 80 -4.5 %, 96 -5 %, 100 -11 %,
+                                   // 128 -10 %, 196 -14 %, 256 -13 %, 300 -15 %, 512 -17 %, 1000 -17 %
 #endif
 
 // Sleef's large-argument lgamma for a dense pass of arguments above 7 (class C: >= 10)
@@ -1116,7 +1122,7 @@ __device__ __forceinline__ void mm_iterate_wave_split(float (&beta)[E], const Ro
 }
 
 template <int E, int G>
-__global__ __launch_bounds__(64, TCLIP_MM_WAVES_SMALL) void k_mm_split(MMArgs a) {
+__global__ __launch_bounds__(64, (E > 16 ? TCLIP_MM_WAVES_LARGE : TCLIP_MM_WAVES_SMALL)) void k_mm_split(MMArgs a) {
     static_assert(E <= TCLIP_SPLIT_MAX_E, "LDS: two words per element");
     __shared__ LogTabEntry tab[16];
     __shared__ float plane0[64 * E];
@@ -2173,7 +2179,7 @@ static void launch_mm_EG(int dead, int rows, hipStream_t st, const MMArgs& a) {
     int grid = (rows + kRowsPerBlock - 1) / kRowsPerBlock;
     if (grid > 256 * 16) grid = 256 * 16;
     if (dead == kMMSplit) {                        // live rows through the class-split kernel where it exists (E <= 16)
-        if constexpr (E <= TCLIP_SPLIT_MAX_E) {
+        if constexpr (E <= TCLIP_SPLIT_MAX_E && E >= TCLIP_SPLIT_MIN_E) {
             constexpr int kSplitRows = 64 / G;           // one wavefront per block
             int sgrid = (rows + kSplitRows - 1) / kSplitRows;
             if (sgrid > 256 * 64) sgrid = 256 * 64;
