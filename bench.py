@@ -18,20 +18,26 @@ reference's sampler), one engine call for the rank's batches, the accuracy tail 
 host assignment), and for N>1 the single RCCL all_gather of the per-task accuracies onto rank 0.
 
 Extra objects on the JSON line:
-  roofline     the dominant kernel k_mm_live, timed live with HIP events around each of its launches
-               on the streams they run on (independent batches use a few internal streams, so
-               launches overlap: `achieved` divides by the time during which at least one launch
-               was running, `avg_launch_ms` is the plain mean launch duration).  The path is fp32
-               vector-ALU bound, so the bound is "valu": achieved = 48
-               flop-equivalents x element-updates executed / kernel time against 157.3 TFLOP/s.
-               `traffic` = HBM-side bytes per launch of that kernel from the PMC passes recorded in
-               profiles/pmc_current.json (FETCH_SIZE + WRITE_SIZE, calibrated on the dword-per-lane
-               copy kernel of the same run), null when that file does not describe this build.
-  secondary    the K=100 workload of round 1 (BASELINE configs[1]), a few steps, same roofline fields.
-  cpu_baseline the torch-eager CPU restatement of the reference loop (oracle/ref_torch.py, kind
-               "port") on this host: K=1000 is ~6 minutes per task on 8 cores, so, as SURVEY.md 8d
-               prescribes, MM iterations of the first and of a later outer iteration plus one M/E-step are timed
-               on a 2-task batch and extrapolated over the MM schedule the GPU run recorded.
+  roofline     the dominant kernels - k_mm_live (first outer iteration) and k_mm_split (the later ones), the MM loop of
+               the live rows - timed live with HIP events around each of their launches on the streams they run on
+               (independent batches use a few internal streams, so launches overlap: `achieved` divides by the time
+               during which at least one launch was running, `avg_launch_ms` is the plain mean launch duration).
+               The path is fp32 vector-ALU bound, so the bound is "valu": achieved = 48
+               flop-equivalents x element-updates executed / kernel time against 157.3 TFLOP/s (the 2.4 GHz sheet
+               value); `measured_clock_ghz` / `frac_at_measured_clock` rescale the peak to the clock the chip held in
+               the committed PMC pass (GRBM_GUI_ACTIVE / 8 / kernel time).  `traffic` = HBM-side bytes per launch from
+               the PMC passes recorded in profiles/pmc_current.json (FETCH_SIZE + WRITE_SIZE, calibrated on the
+               dword-per-lane copy kernel of the same run) next to `traffic_algorithmic_bytes_per_launch` of THAT
+               workload; null when the file does not describe this build.
+  secondary    the other BASELINE.json configs on one GPU, a few steps each, every one with its own roofline and an
+               extrapolated cpu_baseline: `k100` = configs[1] (K=100), `k397_hard` = configs[2] (Hard EM-Dirichlet at
+               K=397 plus SOFT_KMEANS on the same tasks), `fs_k1000` = configs[4] (visual embeddings -> probability
+               front-end -> 4-shot few-shot EM-Dirichlet at K=1000).  `secondary.value` etc. repeat `k100` at the top
+               level of the object (round-2 readers).
+  cpu_baseline the torch-eager CPU restatement of the reference loop (oracle/ref_torch.py, kind "port") on this host:
+               K=1000 is ~6 minutes per task on 8 cores, so, as SURVEY.md 8d prescribes, MM iterations of the first and
+               of a later outer iteration plus one M/E-step are timed on a 2-task batch and extrapolated over the MM
+               schedule the GPU run recorded.
 """
 import argparse
 import json
@@ -60,6 +66,15 @@ HEADLINE = dict(name="k1000", K=1000, tasks_per_batch=125, batches_per_gpu=10, r
 SECONDARY = dict(name="k100", K=100, tasks_per_batch=100, batches_per_gpu=10, rows_per_class=40,
                  text="EM-Dirichlet zero-shot, K=100 (caltech101-sized), 75-query, 1000 tasks per GPU as 10 batches of 100, "
                       "iter=20, iter_mm=1000 (BASELINE.json configs[1])")
+K397_HARD = dict(name="k397_hard", K=397, tasks_per_batch=100, batches_per_gpu=10, rows_per_class=40, method="HARD_EM_DIRICHLET",
+                 iters=10,
+                 text="Hard EM-Dirichlet zero-shot, K=397 (sun397-sized), 75-query, 1000 tasks as 10 batches of 100, iter=10, "
+                      "iter_mm=1000, plus SOFT_KMEANS (iter=20, T=30) on the same tasks (BASELINE.json configs[2])")
+FS_K1000 = dict(name="fs_k1000", K=1000, tasks_per_batch=25, batches_per_gpu=4, shots=4, dim=512, support_rows_per_class=5,
+                query_rows_per_class=20,
+                text="visual embeddings (512-d) -> probability features softmax(30 cos) on the device -> 4-shot few-shot "
+                     "EM-Dirichlet, K=1000, S=4000 support rows per task, 75-query, 100 tasks as 4 batches of 25, iter=20, "
+                     "iter_mm=1000 (BASELINE.json configs[4]; synthetic unit-norm text embeddings, SURVEY.md config-5 note)")
 FLOP_EQ_PER_UPDATE = 48.0
 PEAK_VALU_TFLOPS = 157.3
 PEAK_HBM_GBS = 8000.0
@@ -67,40 +82,55 @@ PMC_FILE = os.path.join(ROOT, "profiles", "pmc_current.json")
 
 
 _CPU_SNIPPET = r"""
-import json, os, sys, time
+import json, os, resource, sys, time
+resource.setrlimit(resource.RLIMIT_AS, ({mem_gb} << 30, {mem_gb} << 30))      # fail with MemoryError rather than take the host down
 sys.path.insert(0, {root!r}); sys.path.insert(0, os.path.join({root!r}, "transductive-clip_amd"))
 import torch
 from oracle import ref_torch
 from tclip_amd import synth
 torch.set_num_threads({threads})
-x_q, _ = synth.make_query_tasks({n_tasks}, {K}, seed=0)
-out = {{}}
+x_q, _ = synth.make_query_tasks({n_tasks}, {K}, seed=0, k_eff={k_eff})
+x_s = y_s = None
+if {shots}:
+    x_s, y_s = synth.make_support({n_tasks}, {K}, {shots}, seed=0)
+    y_s = y_s.squeeze(2)
+out, ran = {{}}, {{}}
 if {warm}:
-    ref_torch.run(x_q, n_class={K}, iters=1, iter_mm=2, lambd={lambd}, hard=False)      # thread pool, allocator
+    ref_torch.run(x_q, x_s, y_s, n_class={K}, iters=1, iter_mm=52, lambd={lambd}, hard={hard})      # thread pool, allocator, page faults
 for iters, mm in {mm_list}:
-    r = ref_torch.run(x_q, n_class={K}, iters=iters, iter_mm=mm, lambd={lambd}, hard=False)
+    r = ref_torch.run(x_q, x_s, y_s, n_class={K}, iters=iters, iter_mm=mm, lambd={lambd}, hard={hard})
     out[str(iters) + "x" + str(mm)] = r["seconds"]
-print(json.dumps({{"seconds": out, "threads": torch.get_num_threads(), "torch": torch.__version__}}))
+    ran[str(iters) + "x" + str(mm)] = [int(v) for v in r["mm_iters"]]
+print(json.dumps({{"seconds": out, "ran": ran, "threads": torch.get_num_threads(), "torch": torch.__version__}}))
 """
 
 
-def cpu_baseline(w, mm_schedule, budget_s=300):
+def cpu_baseline(w, mm_schedule, budget_s=300, iters_total=ITERS):
     """Reference loop on the host CPU (kind "port": oracle/ref_torch.py issues the reference's own
     torch op sequence).  mm_schedule: MM iterations per outer iteration the GPU run recorded for
-    batch 0.  Child process under a time budget: an oversubscribed host cannot stall the bench."""
+    batch 0.  Child process under a time budget and an address-space limit: an oversubscribed or small host
+    cannot stall the bench.  Always a bounded sample: MM iterations of the first and of a later outer iteration
+    and one M/E-step are timed on a 2-task batch and extrapolated over the recorded schedule.
+    Few-shot at K=1000: the reference's (N,S,K,K) support temporary is 16 GB per task at 4 shots, so the sample
+    runs ONE task at ONE shot (4 GB) and the support part of the M-step, linear in S, is scaled to 4 shots."""
     import subprocess
     try:
         usable = len(os.sched_getaffinity(0))
     except AttributeError:
         usable = os.cpu_count() or 1
     threads = max(1, min(usable, 16))
-    K = w["K"]
-    if K >= 397:          # extrapolated from one and two outer iterations with 101 and with 301 MM iterations each
-        n_tasks, mm_list = 2, [(1, 101), (1, 301), (2, 101), (2, 301)]
-    else:                 # affordable in full: one whole batch, whole schedule
-        n_tasks, mm_list = w["tasks_per_batch"], [(ITERS, ITER_MM)]
-    code = _CPU_SNIPPET.format(root=ROOT, threads=threads, n_tasks=n_tasks, K=K, mm_list=mm_list,
-                               lambd=int(K / 5) * N_QUERY, warm=len(mm_list) > 1)
+    K, shots, hard = w["K"], w.get("shots", 0), w.get("method", "") == "HARD_EM_DIRICHLET"
+    mm_list = [(1, 101), (1, 301), (2, 101), (2, 301)]
+    n_tasks, sample_shots = 2, shots
+    if K < 397:                                                     # the reference batch itself fits ((N,Q,K,K) = 300 MB at K = 100)
+        n_tasks, mm_list = w["tasks_per_batch"], [(1, 51), (1, 151), (2, 51), (2, 151)]
+    elif K < 1000:
+        n_tasks = 8                                                 # (N,Q,K,K) = 380 MB at K = 397; the 100-task batch would need 4.7 GB per temporary
+    if shots and K >= 397:
+        n_tasks, sample_shots, mm_list = 1, 1, [(1, 51), (1, 151), (2, 51), (2, 151)]
+    lambd = int(K / 5) * N_QUERY
+    code = _CPU_SNIPPET.format(root=ROOT, threads=threads, n_tasks=n_tasks, K=K, mm_list=mm_list, lambd=lambd, warm=True,
+                               shots=sample_shots, hard=hard, k_eff=(5 if shots else None), mem_gb=40)
     try:
         out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=budget_s)
         info = json.loads(out.stdout.strip().splitlines()[-1])
@@ -108,23 +138,33 @@ def cpu_baseline(w, mm_schedule, budget_s=300):
         return {"value": None, "unit": "tasks/s", "cores": threads, "kind": "port",
                 "sample": f"not measured: {type(e).__name__} within {budget_s}s budget"}
     secs = info["seconds"]
-    if len(mm_list) == 1:
-        total = secs[f"{ITERS}x{ITER_MM}"]
-        return {"value": n_tasks / total, "unit": "tasks/s", "cores": info["threads"], "kind": "port",
-                "sample": f"{n_tasks} tasks (one batch) of the same K={K}, 75-query workload, full {ITERS}x{ITER_MM} "
-                          f"schedule, torch {info['torch']} CPU eager, {total:.1f}s"}
     # an MM iteration costs differently in the first outer iteration (every class alive, alpha near 1) and in the
     # later ones (few live classes, large alpha), so both regimes are timed: all for the n_tasks batch
-    a1, b1, a2, b2 = secs["1x101"], secs["1x301"], secs["2x101"], secs["2x301"]
-    mm_first = (b1 - a1) / 200.0                                   # one MM iteration, first outer iteration
-    mm_later = max((b2 - a2) / 200.0 - mm_first, 0.0)              # one MM iteration, second outer iteration
-    per_me = max(a1 - 101 * mm_first, 0.0)                         # M-step statistics + E-step + criterion, once per outer iteration
+    (_, m0), (_, m1) = mm_list[0], mm_list[1]
+    a1, b1, a2, b2 = (secs[f"{i}x{m}"] for i, m in mm_list)
+    ran = info["ran"]                                               # MM iterations actually executed (the stop test may end a loop early)
+    r_a1, r_b1, r_a2, r_b2 = (ran[f"{i}x{m}"] for i, m in mm_list)
+    d_first = max(r_b1[0] - r_a1[0], 1)
+    mm_first = (b1 - a1) / float(d_first)                           # one MM iteration, first outer iteration
+    d_later = max(r_b2[1] - r_a2[1], 1)
+    mm_later = max(((b2 - a2) - (r_b2[0] - r_a2[0]) * mm_first) / float(d_later), 0.0)      # one MM iteration, second outer iteration
+    per_me = max(a1 - r_a1[0] * mm_first, 0.0)                      # M-step statistics + E-step + criterion, once per outer iteration
+    note = ""
+    if sample_shots != shots:                                       # support statistics are linear in S = K * shots
+        zs = json.loads(subprocess.run([sys.executable, "-c", _CPU_SNIPPET.format(
+            root=ROOT, threads=threads, n_tasks=n_tasks, K=K, mm_list=[(1, m0)], lambd=lambd, warm=True, shots=0, hard=hard,
+            k_eff=5, mem_gb=40)], capture_output=True, text=True, timeout=budget_s).stdout.strip().splitlines()[-1])["seconds"]
+        per_me_zs = max(zs[f"1x{m0}"] - m0 * mm_first, 0.0)       # (a loop of m0 <= 51 iterations cannot stop early)
+        support_part = max(per_me - per_me_zs, 0.0)
+        note = (f"; sampled at {sample_shots} shot (M/E-step {per_me:.2f}s, of which support statistics {support_part:.2f}s, "
+                f"linear in S) and scaled to {shots} shots")
+        per_me = per_me_zs + support_part * shots / sample_shots
     total = len(mm_schedule) * per_me + mm_schedule[0] * mm_first + sum(mm_schedule[1:]) * mm_later
     return {"value": n_tasks / total, "unit": "tasks/s", "cores": info["threads"], "kind": "port",
-            "sample": f"{n_tasks}-task batch of the same K={K}, 75-query workload, timed: 1 outer iteration with 101 ({a1:.1f}s) and "
-                      f"301 ({b1:.1f}s) MM iterations, 2 outer iterations with 101 ({a2:.1f}s) and 301 ({b2:.1f}s) -> "
+            "sample": f"{n_tasks}-task batch of the same K={K}, 75-query workload, timed: 1 outer iteration with {r_a1[0]} ({a1:.1f}s) and "
+                      f"{r_b1[0]} ({b1:.1f}s) MM iterations, 2 outer iterations with {r_a2} ({a2:.1f}s) and {r_b2} ({b2:.1f}s) -> "
                       f"{1e3 * mm_first:.1f} / {1e3 * mm_later:.1f} ms per MM iteration in the first / a later outer iteration, "
-                      f"{per_me:.2f}s per M/E-step; extrapolated over the recorded schedule ({mm_schedule[0]} + "
+                      f"{per_me:.2f}s per M/E-step{note}; extrapolated over the recorded schedule ({mm_schedule[0]} + "
                       f"{int(sum(mm_schedule[1:]))} MM iterations in {len(mm_schedule)} outer iterations) = {total:.0f}s "
                       f"(SURVEY.md 8d); torch {info['torch']} CPU eager",
             "extrapolated": True}
@@ -146,7 +186,7 @@ def roofline_of(prof, steps, K, pmc_key):
     # once per launch = 12 bytes per element per <=51-iteration launch
     rows_bytes = 12.0 * updates / 50.0
     hbm_gbs = rows_bytes / (mm_ms * 1e-3) / 1e9 if mm_ms > 0 else 0.0
-    out = {"bound": "valu", "kernel": "k_mm_live", "achieved": achieved, "peak": PEAK_VALU_TFLOPS, "unit": "TFLOP/s",
+    out = {"bound": "valu", "kernel": "k_mm_live + k_mm_split (MM loop of the live rows)", "achieved": achieved, "peak": PEAK_VALU_TFLOPS, "unit": "TFLOP/s",
            "frac": achieved / PEAK_VALU_TFLOPS, "traffic": None,
            "flop_eq_per_element_update": FLOP_EQ_PER_UPDATE,
            "element_updates_executed_per_step": updates / steps,
@@ -161,10 +201,18 @@ def roofline_of(prof, steps, K, pmc_key):
     pmc = load_pmc()
     if pmc and pmc_key in pmc:
         e = pmc[pmc_key]
+        # traffic and the algorithmic bytes it is to be compared with come from the SAME (smaller) PMC workload
         out["traffic"] = e.get("traffic_bytes_per_launch")
+        out["traffic_algorithmic_bytes_per_launch"] = e.get("algorithmic_bytes_per_launch")
+        if out["traffic"] and e.get("algorithmic_bytes_per_launch"):
+            out["traffic_over_algorithmic"] = out["traffic"] / e["algorithmic_bytes_per_launch"]
+        if e.get("clock_ghz"):                       # the clock the chip held under this kernel: GRBM_GUI_ACTIVE / 8 / kernel time
+            out["measured_clock_ghz"] = e["clock_ghz"]
+            out["peak_at_measured_clock"] = PEAK_VALU_TFLOPS * e["clock_ghz"] / 2.4
+            out["frac_at_measured_clock"] = achieved / out["peak_at_measured_clock"]
         out["traffic_source"] = {k: e.get(k) for k in ("file", "workload", "fetch_bytes_per_launch", "write_bytes_per_launch",
                                                        "algorithmic_bytes_per_launch", "calibration", "lane_instr_per_update",
-                                                       "wait_frac", "scratch_bytes_per_lane", "commit")}
+                                                       "valu_busy_frac", "wait_frac", "scratch_bytes_per_lane", "clock_ghz", "commit")}
     return out
 
 
@@ -212,40 +260,49 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    def prepare(w, n_ranks):
+    def prepare(w, n_ranks, method="EM_DIRICHLET", iters=ITERS):
         """Feature table in HBM + the index stream of every batch (same on every rank)."""
         K = w["K"]
         feats, labels = synth.make_feature_table(K, w["rows_per_class"], seed=2020)
         n_tasks = w["tasks_per_batch"] * w["batches_per_gpu"] * (8 if args.scaling == "strong" else n_ranks)
-        cfg = CfgNode(iter=ITERS, iter_mm=ITER_MM, num_classes_test=K, n_class=K, n_query=N_QUERY, k_eff=5, T=30,
+        cfg = CfgNode(iter=iters, iter_mm=ITER_MM, num_classes_test=K, n_class=K, n_query=N_QUERY, k_eff=5, T=30,
                       use_softmax_feature=True, graph_matching=True, shots=0, number_tasks=n_tasks,
-                      batch_size=w["tasks_per_batch"], name_method="EM_DIRICHLET", used_test_set="test")
+                      batch_size=w["tasks_per_batch"], name_method=method, used_test_set="test")
         ev = Evaluator_zero_shot(device=dev, args=cfg, log_file=None)
         random.seed(2020); np.random.seed(2020); torch.manual_seed(2020)     # main.py:42-46
         idx = ev.sample_indices(labels.numpy())
         return ev, feats.to(dev), labels.to(dev), idx
 
-    def run_steps(ev, table, labels, idx, warmup, steps):
+    def timed(step, warmup, steps):
+        """`warmup` untimed and `steps` timed calls of step(); returns (seconds, profile, last result, per-rank seconds)."""
         for _ in range(warmup):
-            ev.evaluate_tasks(None, table, labels, indices=idx)
+            step()
         fence()
         engine.profile_enable(True)
         t0 = time.perf_counter()
         for _ in range(steps):
-            acc_mean, _ = ev.evaluate_tasks(None, table, labels, indices=idx)
+            res = step()
         fence()
         elapsed = time.perf_counter() - t0
         prof = engine.profile_collect()
         engine.profile_enable(False)
+        per_rank = [elapsed]
         if dist_on:
-            t = torch.tensor([elapsed], device=dev if args.backend == "nccl" else "cpu", dtype=torch.float64)
-            dist.all_reduce(t, op=dist.ReduceOp.MAX)
-            elapsed = float(t.item())
-        return elapsed, prof, acc_mean
+            where = dev if args.backend == "nccl" else "cpu"
+            mine = torch.tensor([elapsed], device=where, dtype=torch.float64)
+            every = [torch.zeros_like(mine) for _ in range(world)]
+            dist.all_gather(every, mine)
+            per_rank = [float(t.item()) for t in every]
+            elapsed = max(per_rank)                      # the job is done when its slowest rank is
+        return elapsed, prof, res, per_rank
+
+    def run_steps(ev, table, labels, idx, warmup, steps):
+        e, prof, res, per_rank = timed(lambda: ev.evaluate_tasks(None, table, labels, indices=idx), warmup, steps)
+        return e, prof, res[0], per_rank
 
     head = HEADLINE if args.workload == "k1000" else SECONDARY
     ev, table, labels, idx = prepare(head, world)
-    elapsed, prof, acc_mean = run_steps(ev, table, labels, idx, args.warmup, args.steps)
+    elapsed, prof, acc_mean, per_rank = run_steps(ev, table, labels, idx, args.warmup, args.steps)
     steps = max(args.steps, 1)
     mm_iters = ev.last_method.mm_iters                  # (local batches, iters)
     line = None
@@ -255,6 +312,7 @@ def main():
         K = head["K"]
         roof = roofline_of(prof, steps, K, head["name"])
         roof["element_updates_reference_semantics_per_step"] = float(K) ** 2 * head["tasks_per_batch"] * float(mm_iters.sum())
+        preds = ev.last_task_predictions                 # what the one collective delivered: (batches, tasks per batch, 75) int32
         line = {
             "metric": "transductive tasks/sec (75-query EM-Dirichlet)",
             "value": tasks / elapsed, "unit": "tasks/s", "n_gpus": world, "steps": args.steps,
@@ -262,28 +320,108 @@ def main():
             "scaling": args.scaling, "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": head["text"], "n_class": K, "n_query": N_QUERY, "tasks_per_batch": head["tasks_per_batch"],
                        "batches_per_gpu": head["batches_per_gpu"] * (8 // world if args.scaling == "strong" else 1), "tasks_total": job,
-                       "parallelism": f"batch-sharded x{world}, one all_gather of per-task accuracies",
+                       "parallelism": f"batch-sharded x{world}, one all_gather of per-task predictions (int32 x 75), accuracies, "
+                                      f"per-batch criterions and MM counts",
                        "path": "Evaluator_zero_shot.evaluate_tasks (device gather from a 50-rows-per-class synthetic table, "
                                "engine, accuracy tail, gather)",
-                       "mean_accuracy": float(acc_mean), "mm_iters_batch0": mm_iters[0].tolist()},
+                       "mean_accuracy": float(acc_mean), "mm_iters_batch0": mm_iters[0].tolist(),
+                       "gathered": {"predictions": list(preds.shape), "criterions": list(ev.last_batch_criterions.shape),
+                                    "mm_iters": list(ev.last_batch_mm_iters.shape)}},
             "roofline": roof,
         }
+        if dist_on:
+            line["ranks_seen"] = dist.get_world_size()
+            line["backend"] = dist.get_backend()
+            line["rank_step_ms"] = {"min": 1e3 * min(per_rank) / steps, "max": 1e3 * max(per_rank) / steps,
+                                    "all": [1e3 * t / steps for t in per_rank]}
     del ev, table, labels, idx
     torch.cuda.empty_cache()
 
+    def zero_shot_secondary(w, method="EM_DIRICHLET", iters=ITERS, warmup=1, n_steps=3):
+        ev2, table2, labels2, idx2 = prepare(w, 1, method, iters)
+        e2, prof2, acc2, _ = run_steps(ev2, table2, labels2, idx2, warmup, n_steps)
+        n_tasks = w["tasks_per_batch"] * w["batches_per_gpu"]
+        sched = ev2.last_method.mm_iters[0].tolist()
+        obj = {"workload": w["text"], "value": n_steps * n_tasks / e2, "unit": "tasks/s", "steps": n_steps, "warmup": warmup,
+               "ms_per_step": 1e3 * e2 / n_steps, "mean_accuracy": float(acc2), "mm_iters_batch0": sched,
+               "roofline": roofline_of(prof2, n_steps, w["K"], w["name"])}
+        return obj, (ev2, table2, labels2, idx2), sched
+
     if world == 1 and not args.no_secondary and args.workload == "k1000":
-        ev2, table2, labels2, idx2 = prepare(SECONDARY, 1)
-        e2, prof2, acc2 = run_steps(ev2, table2, labels2, idx2, 1, 3)
-        roof2 = roofline_of(prof2, 3, SECONDARY["K"], SECONDARY["name"])
-        line["secondary"] = {"workload": SECONDARY["text"], "value": 3 * 1000 / e2, "unit": "tasks/s", "steps": 3, "warmup": 1,
-                             "ms_per_step": 1e3 * e2 / 3, "mean_accuracy": float(acc2),
-                             "mm_iters_batch0": ev2.last_method.mm_iters[0].tolist(), "roofline": roof2}
-        del ev2, table2, labels2, idx2
+        sec = {}
+        # ---- configs[1]: K = 100
+        obj, keep, sched = zero_shot_secondary(SECONDARY)
+        if not args.no_cpu_baseline:
+            obj["cpu_baseline"] = cpu_baseline(SECONDARY, sched, budget_s=60)
+        sec["k100"] = obj
+        del keep
         torch.cuda.empty_cache()
+        # ---- configs[2]: Hard EM-Dirichlet at K = 397, then SOFT_KMEANS on the same tasks
+        obj, (ev2, table2, labels2, idx2), sched = zero_shot_secondary(K397_HARD, "HARD_EM_DIRICHLET", K397_HARD["iters"], 1, 2)
+        ev3 = Evaluator_zero_shot(device=dev, args=CfgNode(dict(ev2.args, name_method="SOFT_KMEANS", iter=20)), log_file=None)
+        e3, _, acc3, _ = run_steps(ev3, table2, labels2, idx2, 1, 2)
+        T, K3 = K397_HARD["tasks_per_batch"] * K397_HARD["batches_per_gpu"], K397_HARD["K"]
+        # algorithmic HBM bytes of one SOFT_KMEANS iteration: statistics (u, z in; w out), distances (w, z in; logits out),
+        # softmax (logits in; u out) = 4 B x (6 T Q K + 2 T K K)
+        skm_bytes = 20 * 4.0 * (6.0 * T * N_QUERY * K3 + 2.0 * T * K3 * K3)
+        skm_flop = 20 * 5.0 * T * N_QUERY * K3 * K3                  # distances 3 flop per (q, k, d), statistics 2
+        obj["soft_kmeans"] = {"value": 2 * T / e3, "unit": "tasks/s", "steps": 2, "warmup": 1, "ms_per_step": 1e3 * e3 / 2,
+                              "mean_accuracy": float(acc3),
+                              "roofline": {"bound": "hbm", "kernel": "whole SOFT_KMEANS step (k_mstats_rows, k_kmeans_logits_rows, k_softmax)",
+                                           "achieved": skm_bytes / (e3 / 2) / 1e9, "peak": PEAK_HBM_GBS, "unit": "GB/s",
+                                           "frac": skm_bytes / (e3 / 2) / 1e9 / PEAK_HBM_GBS, "traffic": None,
+                                           "algorithmic_bytes_per_step": skm_bytes,
+                                           "fp32_tflops_of_the_two_contractions": skm_flop / (e3 / 2) / 1e12,
+                                           "note": "sums rebuilt in torch's association order (no MFMA): L2-resident re-reads of the "
+                                                   "task's feature block, not HBM, bound this step"}}
+        if not args.no_cpu_baseline:
+            obj["cpu_baseline"] = cpu_baseline(K397_HARD, sched, budget_s=60)
+        sec["k397_hard"] = obj
+        del ev2, ev3, table2, labels2, idx2
+        torch.cuda.empty_cache()
+        # ---- configs[4]: visual embeddings -> probability features -> 4-shot few-shot EM-Dirichlet at K = 1000
+        from src.eval_few_shot import Evaluator_few_shot
+        from tclip_amd import features
+        w = FS_K1000
+        K4, D = w["K"], w["dim"]
+        gen = torch.Generator().manual_seed(2024)
+        text = torch.randn(K4, D, generator=gen)
+        text /= text.norm(dim=-1, keepdim=True)
+        lab_s = torch.arange(K4).repeat_interleave(w["support_rows_per_class"])
+        lab_q = torch.arange(K4).repeat_interleave(w["query_rows_per_class"])
+        vis_s = (text[lab_s] * 2.0 + torch.randn(len(lab_s), D, generator=gen)).to(dev)
+        vis_q = (text[lab_q] * 2.0 + torch.randn(len(lab_q), D, generator=gen)).to(dev)
+        text_d = text.to(dev)
+        n_tasks = w["tasks_per_batch"] * w["batches_per_gpu"]
+        cfg = CfgNode(iter=ITERS, iter_mm=ITER_MM, num_classes_test=K4, n_class=K4, n_query=N_QUERY, k_eff=5, T=30,
+                      use_softmax_feature=True, graph_matching=True, shots=w["shots"], number_tasks=n_tasks,
+                      batch_size=w["tasks_per_batch"], name_method="EM_DIRICHLET", used_test_set="test", tunable=False)
+        ev4 = Evaluator_few_shot(device=dev, args=cfg, log_file=None)
+        random.seed(2020); np.random.seed(2020); torch.manual_seed(2020)
+        idx4 = ev4.sample_indices(lab_s.numpy(), lab_q.numpy())
+
+        def fs_step():                                   # the front-end is part of the step
+            tab_s = features.probability_features(vis_s, text_d, 30.0)
+            tab_q = features.probability_features(vis_q, text_d, 30.0)
+            return ev4.evaluate_tasks(None, tab_s, lab_s, tab_q, lab_q, indices=idx4)
+
+        e4, prof4, res4, _ = timed(fs_step, 1, 2)
+        sched = ev4.last_method.mm_iters[0].tolist()
+        obj = {"workload": w["text"], "value": 2 * n_tasks / e4, "unit": "tasks/s", "steps": 2, "warmup": 1, "ms_per_step": 1e3 * e4 / 2,
+               "mean_accuracy": float(res4[0]), "mm_iters_batch0": sched, "roofline": roofline_of(prof4, 2, K4, w["name"]),
+               "support_rows_per_task": K4 * w["shots"],
+               "note": "few-shot has no dead rows: all K rows of every task iterate in every outer iteration "
+                       "(roofline.element_updates_executed_per_step counts them)"}
+        if not args.no_cpu_baseline:
+            obj["cpu_baseline"] = cpu_baseline(w, sched, budget_s=90)
+        sec["fs_k1000"] = obj
+        del ev4, vis_s, vis_q
+        torch.cuda.empty_cache()
+        line["secondary"] = dict(sec["k100"], **{k: v for k, v in sec.items()})
 
     if rank == 0:
         if world == 1 and not args.no_cpu_baseline:
-            line["cpu_baseline"] = cpu_baseline(head, mm_iters[0].tolist())
+            line["cpu_baseline"] = cpu_baseline(head, mm_iters[0].tolist(), budget_s=120)
         print(json.dumps(line), flush=True)
     if dist_on:
         dist.barrier()

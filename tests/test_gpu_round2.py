@@ -223,3 +223,28 @@ def test_bench_multi_rank_path_on_one_gpu():
     assert d["n_gpus"] == 2 and d["scaling"] == "weak" and d["config"]["tasks_total"] == 2000
     assert d["value"] > 0 and abs(d["value"] - 2000 / (d["ms_per_step"] * 1e-3)) < 1e-6 * d["value"]
     assert 0.5 < d["config"]["mean_accuracy"] < 1.0 and "roofline" in d and "cpu_baseline" not in d
+    # what the first hardware scaling curve will show: ranks seen, backend, per-rank step times, and what the one gather carried
+    assert d["ranks_seen"] == 2 and d["backend"] == "gloo"
+    assert len(d["rank_step_ms"]["all"]) == 2 and d["rank_step_ms"]["max"] == pytest.approx(d["ms_per_step"])
+    assert d["config"]["gathered"] == {"predictions": [20, 100, 75], "criterions": [20, 20], "mm_iters": [20, 20]}
+
+
+def test_bench_eight_rank_launch_on_one_gpu():
+    """The command the driver will use for the N = 8 point of the scaling curve, with the eight ranks sharing the one GPU
+    of this box (gloo, --single-device, K = 100 workload, one step): rendezvous, eight processes loading the library,
+    round-robin batches (10 per rank), the packed gather of 80 batches, one JSON line."""
+    import subprocess
+    import sys
+    from conftest import ROOT
+    port = 29900 + os.getpid() % 90
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "8", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.join(ROOT, "bench.py"), "--gpus", "8", "--steps", "1", "--warmup", "0",
+           "--workload", "k100", "--backend", "gloo", "--single-device"]
+    out = subprocess.run(cmd, capture_output=True, text=True, timeout=900)
+    assert out.returncode == 0, out.stderr[-2000:]
+    lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, out.stdout[-2000:]
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 8 and d["ranks_seen"] == 8 and d["config"]["tasks_total"] == 8000
+    assert d["config"]["gathered"]["predictions"] == [80, 100, 75] and len(d["rank_step_ms"]["all"]) == 8
+    assert 0.5 < d["config"]["mean_accuracy"] < 1.0
