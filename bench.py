@@ -71,7 +71,8 @@ K397_HARD = dict(name="k397_hard", K=397, tasks_per_batch=100, batches_per_gpu=1
                  text="Hard EM-Dirichlet zero-shot, K=397 (sun397-sized), 75-query, 1000 tasks as 10 batches of 100, iter=10, "
                       "iter_mm=1000, plus SOFT_KMEANS (iter=20, T=30) on the same tasks (BASELINE.json configs[2])")
 FS_K1000 = dict(name="fs_k1000", K=1000, tasks_per_batch=25, batches_per_gpu=4, shots=4, dim=512, support_rows_per_class=5,
-                query_rows_per_class=20,
+                query_rows_per_class=20, signal=6.0,      # embedding = 6 x class direction + unit noise: cos 0.26 to the own class text,
+                                                          # probability ~0.5 on it at T = 30 (CLIP-like peakedness)
                 text="visual embeddings (512-d) -> probability features softmax(30 cos) on the device -> 4-shot few-shot "
                      "EM-Dirichlet, K=1000, S=4000 support rows per task, 75-query, 100 tasks as 4 batches of 25, iter=20, "
                      "iter_mm=1000 (BASELINE.json configs[4]; synthetic unit-norm text embeddings, SURVEY.md config-5 note)")
@@ -389,8 +390,8 @@ def main():
         text /= text.norm(dim=-1, keepdim=True)
         lab_s = torch.arange(K4).repeat_interleave(w["support_rows_per_class"])
         lab_q = torch.arange(K4).repeat_interleave(w["query_rows_per_class"])
-        vis_s = (text[lab_s] * 2.0 + torch.randn(len(lab_s), D, generator=gen)).to(dev)
-        vis_q = (text[lab_q] * 2.0 + torch.randn(len(lab_q), D, generator=gen)).to(dev)
+        vis_s = (text[lab_s] * FS_K1000["signal"] + torch.randn(len(lab_s), D, generator=gen)).to(dev)
+        vis_q = (text[lab_q] * FS_K1000["signal"] + torch.randn(len(lab_q), D, generator=gen)).to(dev)
         text_d = text.to(dev)
         n_tasks = w["tasks_per_batch"] * w["batches_per_gpu"]
         cfg = CfgNode(iter=ITERS, iter_mm=ITER_MM, num_classes_test=K4, n_class=K4, n_query=N_QUERY, k_eff=5, T=30,

@@ -13,6 +13,8 @@ for set in "${PASSES[@]}"; do
   timeout 600 rocprofv3 --kernel-trace --pmc $set --output-format csv -d $R/gpurun_out/pmcdir_$i -- python3 $R/scripts/prof_small.py "$@" > $R/gpurun_out/pmc_$KEY.pass$i.log 2>&1
   f=$(find $R/gpurun_out/pmcdir_$i -name "*counter_collection.csv" | head -1)
   cp $f $R/gpurun_out/pmc_$KEY.pass$i.csv
+  t=$(find $R/gpurun_out/pmcdir_$i -name "*kernel_trace.csv" | head -1)
+  [ -n "$t" ] && cp $t $R/gpurun_out/pmc_$KEY.trace$i.csv
   rm -rf $R/gpurun_out/pmcdir_$i
   i=$((i+1))
 done
@@ -29,6 +31,32 @@ for f in sorted(glob.glob(f"{R}/gpurun_out/pmc_{key}.pass*.csv")):
         if ("k_mm_live" in k and "false" in k) or "k_mm_split" in k:
             extra = {"scratch_bytes_per_lane": int(r.get("Scratch_Size", 0) or 0), "vgpr": int(r.get("VGPR_Count", 0) or 0),
                      "lds_bytes_per_block": int(r.get("LDS_Block_Size", 0) or 0)}
+# the clock the chip held under the MM kernels: GRBM_GUI_ACTIVE (summed over the 8 XCDs) / 8 / kernel time, both from the
+# pass that counted GRBM_GUI_ACTIVE (kernel time from that pass's kernel trace, joined on the dispatch id)
+clock_ghz = None
+try:
+    gui = collections.defaultdict(float)
+    for f in sorted(glob.glob(f"{R}/gpurun_out/pmc_{key}.pass*.csv")):
+        rows = list(csv.DictReader(open(f)))
+        if not any(r["Counter_Name"] == "GRBM_GUI_ACTIVE" for r in rows):
+            continue
+        i = re.search(r"pass(\d+)", f).group(1)
+        for r in rows:
+            if r["Counter_Name"] == "GRBM_GUI_ACTIVE" and (("k_mm_live" in r["Kernel_Name"] and "false" in r["Kernel_Name"]) or "k_mm_split" in r["Kernel_Name"]):
+                gui[r["Dispatch_Id"]] += float(r["Counter_Value"])
+        dur = {}
+        if rows and "Start_Timestamp" in rows[0] and "End_Timestamp" in rows[0]:
+            for r in rows:
+                dur[r["Dispatch_Id"]] = float(r["End_Timestamp"]) - float(r["Start_Timestamp"])
+        else:
+            for r in csv.DictReader(open(f"{R}/gpurun_out/pmc_{key}.trace{i}.csv")):
+                dur[r.get("Dispatch_Id", r.get("Correlation_Id"))] = float(r["End_Timestamp"]) - float(r["Start_Timestamp"])
+        # long dispatches only: the quotient reads high on dispatches shorter than ~0.3 ms (guide, DVFS section)
+        ids = [d for d in gui if d in dur and dur[d] > 3e5]
+        if ids:
+            clock_ghz = sum(gui[d] for d in ids) / 8.0 / sum(dur[d] for d in ids)
+except Exception as e:
+    print("clock not derived:", e)
 log = open(f"{R}/gpurun_out/pmc_{key}.pass0.log").read()
 runs = re.findall(r"K=(\d+) B=(\d+) N=(\d+) iters=(\d+) .*?launches=(\d+) updates=([0-9.e+]+)", log)
 K, B, N, iters, launches, updates = runs[-1]
@@ -60,6 +88,7 @@ out = {
                        "valu_active_quad_cycles": agg[k]["SQ_ACTIVE_INST_VALU"], "gui_active": agg[k]["GRBM_GUI_ACTIVE"],
                        "valu_busy_frac": agg[k]["SQ_ACTIVE_INST_VALU"] * 4 / max(agg[k]["GRBM_GUI_ACTIVE"] / 8 * 1024, 1)} for k in mm},
     "valu_busy_frac": a["SQ_ACTIVE_INST_VALU"] * 4 / max(a["GRBM_GUI_ACTIVE"] / 8 * 1024, 1),
+    "clock_ghz": clock_ghz,
     "wait_frac": a["SQ_WAIT_ANY"] / a["SQ_WAVE_CYCLES"], "issue_stall_frac": a["SQ_WAIT_INST_ANY"] / a["SQ_WAVE_CYCLES"],
     "active_frac": a["SQ_ACTIVE_INST_ANY"] / a["SQ_WAVE_CYCLES"],
     "trans_frac_of_valu": a["SQ_INSTS_VALU_TRANS_F32"] / a["SQ_INSTS_VALU"],
@@ -77,4 +106,4 @@ others = {k: {c: v for c, v in agg[k].items()} for k in sorted(agg, key=lambda k
 json.dump({"summary": out, "counters_by_kernel": others}, open(f"{R}/gpurun_out/pmc_{key}.json", "w"), indent=1)
 print(json.dumps(out, indent=1))
 PY
-rm -f $R/gpurun_out/pmc_$KEY.pass*.csv
+rm -f $R/gpurun_out/pmc_$KEY.pass*.csv $R/gpurun_out/pmc_$KEY.trace*.csv
