@@ -224,7 +224,9 @@ def main():
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-secondary", action="store_true")
-    ap.add_argument("--workload", choices=["k1000", "k100"], default="k1000", help="headline workload (k100: round-1 shape)")
+    ap.add_argument("--workload", choices=["k1000", "k100", "k397_hard", "fs_k1000"], default="k1000",
+                    help="k1000: the headline (default); k100: the round-1 shape as the headline; k397_hard / fs_k1000: only that "
+                         "secondary workload (BASELINE configs[2] / configs[4]), for profiling")
     ap.add_argument("--scaling", choices=["weak", "strong"], default="weak",
                     help="weak (default): 10 batches per GPU, N = 8 is configs[3]; strong: the whole configs[3] job (80 batches of 125 "
                          "K = 1000 tasks) on N GPUs - 90 s per step on one GPU")
@@ -301,6 +303,98 @@ def main():
         e, prof, res, per_rank = timed(lambda: ev.evaluate_tasks(None, table, labels, indices=idx), warmup, steps)
         return e, prof, res[0], per_rank
 
+    def zero_shot_secondary(w, method="EM_DIRICHLET", iters=ITERS, warmup=1, n_steps=3):
+        ev2, table2, labels2, idx2 = prepare(w, 1, method, iters)
+        e2, prof2, acc2, _ = run_steps(ev2, table2, labels2, idx2, warmup, n_steps)
+        n_tasks = w["tasks_per_batch"] * w["batches_per_gpu"]
+        sched = ev2.last_method.mm_iters[0].tolist()
+        obj = {"workload": w["text"], "value": n_steps * n_tasks / e2, "unit": "tasks/s", "steps": n_steps, "warmup": warmup,
+               "ms_per_step": 1e3 * e2 / n_steps, "mean_accuracy": float(acc2), "mm_iters_batch0": sched,
+               "roofline": roofline_of(prof2, n_steps, w["K"], w["name"])}
+        return obj, (ev2, table2, labels2, idx2), sched
+
+    def run_k100():                                      # configs[1]: K = 100
+        obj, keep, sched = zero_shot_secondary(SECONDARY)
+        if not args.no_cpu_baseline:
+            obj["cpu_baseline"] = cpu_baseline(SECONDARY, sched, budget_s=60)
+        del keep
+        torch.cuda.empty_cache()
+        return obj
+
+    def run_k397_hard():                                 # configs[2]: Hard EM-Dirichlet at K = 397, then SOFT_KMEANS on the same tasks
+        obj, (ev2, table2, labels2, idx2), sched = zero_shot_secondary(K397_HARD, "HARD_EM_DIRICHLET", K397_HARD["iters"], 1, 2)
+        ev3 = Evaluator_zero_shot(device=dev, args=CfgNode(dict(ev2.args, name_method="SOFT_KMEANS", iter=20)), log_file=None)
+        e3, _, acc3, _ = run_steps(ev3, table2, labels2, idx2, 1, 2)
+        T, K3 = K397_HARD["tasks_per_batch"] * K397_HARD["batches_per_gpu"], K397_HARD["K"]
+        # algorithmic HBM bytes of one SOFT_KMEANS iteration: statistics (u, z in; w out), distances (w, z in; logits out),
+        # softmax (logits in; u out) = 4 B x (6 T Q K + 2 T K K)
+        skm_bytes = 20 * 4.0 * (6.0 * T * N_QUERY * K3 + 2.0 * T * K3 * K3)
+        skm_flop = 20 * 5.0 * T * N_QUERY * K3 * K3                  # distances 3 flop per (q, k, d), statistics 2
+        obj["soft_kmeans"] = {"value": 2 * T / e3, "unit": "tasks/s", "steps": 2, "warmup": 1, "ms_per_step": 1e3 * e3 / 2,
+                              "mean_accuracy": float(acc3),
+                              "roofline": {"bound": "hbm", "kernel": "whole SOFT_KMEANS step (k_mstats_rows, k_kmeans_logits_rows, k_softmax)",
+                                           "achieved": skm_bytes / (e3 / 2) / 1e9, "peak": PEAK_HBM_GBS, "unit": "GB/s",
+                                           "frac": skm_bytes / (e3 / 2) / 1e9 / PEAK_HBM_GBS, "traffic": None,
+                                           "algorithmic_bytes_per_step": skm_bytes,
+                                           "fp32_tflops_of_the_two_contractions": skm_flop / (e3 / 2) / 1e12,
+                                           "note": "sums rebuilt in torch's association order (no MFMA): L2-resident re-reads of the "
+                                                   "task's feature block, not HBM, bound this step"}}
+        if not args.no_cpu_baseline:
+            obj["cpu_baseline"] = cpu_baseline(K397_HARD, sched, budget_s=60)
+        del ev2, ev3, table2, labels2, idx2
+        torch.cuda.empty_cache()
+        return obj
+
+    def run_fs_k1000():                                  # configs[4]: visual embeddings -> probability features -> 4-shot few-shot EM-Dirichlet at K = 1000
+        from src.eval_few_shot import Evaluator_few_shot
+        from tclip_amd import features
+        w = FS_K1000
+        K4, D = w["K"], w["dim"]
+        gen = torch.Generator().manual_seed(2024)
+        text = torch.randn(K4, D, generator=gen)
+        text /= text.norm(dim=-1, keepdim=True)
+        lab_s = torch.arange(K4).repeat_interleave(w["support_rows_per_class"])
+        lab_q = torch.arange(K4).repeat_interleave(w["query_rows_per_class"])
+        vis_s = (text[lab_s] * FS_K1000["signal"] + torch.randn(len(lab_s), D, generator=gen)).to(dev)
+        vis_q = (text[lab_q] * FS_K1000["signal"] + torch.randn(len(lab_q), D, generator=gen)).to(dev)
+        text_d = text.to(dev)
+        n_tasks = w["tasks_per_batch"] * w["batches_per_gpu"]
+        cfg = CfgNode(iter=ITERS, iter_mm=ITER_MM, num_classes_test=K4, n_class=K4, n_query=N_QUERY, k_eff=5, T=30,
+                      use_softmax_feature=True, graph_matching=True, shots=w["shots"], number_tasks=n_tasks,
+                      batch_size=w["tasks_per_batch"], name_method="EM_DIRICHLET", used_test_set="test", tunable=False)
+        ev4 = Evaluator_few_shot(device=dev, args=cfg, log_file=None)
+        random.seed(2020); np.random.seed(2020); torch.manual_seed(2020)
+        idx4 = ev4.sample_indices(lab_s.numpy(), lab_q.numpy())
+
+        def fs_step():                                   # the front-end is part of the step
+            tab_s = features.probability_features(vis_s, text_d, 30.0)
+            tab_q = features.probability_features(vis_q, text_d, 30.0)
+            return ev4.evaluate_tasks(None, tab_s, lab_s, tab_q, lab_q, indices=idx4)
+
+        e4, prof4, res4, _ = timed(fs_step, 1, 2)
+        sched = ev4.last_method.mm_iters[0].tolist()
+        obj = {"workload": w["text"], "value": 2 * n_tasks / e4, "unit": "tasks/s", "steps": 2, "warmup": 1, "ms_per_step": 1e3 * e4 / 2,
+               "mean_accuracy": float(res4[0]), "mm_iters_batch0": sched, "roofline": roofline_of(prof4, 2, K4, w["name"]),
+               "support_rows_per_task": K4 * w["shots"],
+               "note": "few-shot has no dead rows: all K rows of every task iterate in every outer iteration "
+                       "(roofline.element_updates_executed_per_step counts them)"}
+        if not args.no_cpu_baseline:
+            obj["cpu_baseline"] = cpu_baseline(w, sched, budget_s=90)
+        del ev4, vis_s, vis_q
+        torch.cuda.empty_cache()
+        return obj
+
+    runners = {"k100": run_k100, "k397_hard": run_k397_hard, "fs_k1000": run_fs_k1000}
+
+    if args.workload in ("k397_hard", "fs_k1000"):       # one secondary alone (profiling); single GPU
+        if world != 1:
+            raise SystemExit("--workload k397_hard / fs_k1000 runs on one GPU")
+        obj = runners[args.workload]()
+        print(json.dumps(dict({"metric": "transductive tasks/sec (75-query EM-Dirichlet)", "n_gpus": 1, "higher_is_better": True,
+                               "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+                               "config": {"workload": obj["workload"]}}, **obj)), flush=True)
+        return
+
     head = HEADLINE if args.workload == "k1000" else SECONDARY
     ev, table, labels, idx = prepare(head, world)
     elapsed, prof, acc_mean, per_rank = run_steps(ev, table, labels, idx, args.warmup, args.steps)
@@ -338,87 +432,9 @@ def main():
     del ev, table, labels, idx
     torch.cuda.empty_cache()
 
-    def zero_shot_secondary(w, method="EM_DIRICHLET", iters=ITERS, warmup=1, n_steps=3):
-        ev2, table2, labels2, idx2 = prepare(w, 1, method, iters)
-        e2, prof2, acc2, _ = run_steps(ev2, table2, labels2, idx2, warmup, n_steps)
-        n_tasks = w["tasks_per_batch"] * w["batches_per_gpu"]
-        sched = ev2.last_method.mm_iters[0].tolist()
-        obj = {"workload": w["text"], "value": n_steps * n_tasks / e2, "unit": "tasks/s", "steps": n_steps, "warmup": warmup,
-               "ms_per_step": 1e3 * e2 / n_steps, "mean_accuracy": float(acc2), "mm_iters_batch0": sched,
-               "roofline": roofline_of(prof2, n_steps, w["K"], w["name"])}
-        return obj, (ev2, table2, labels2, idx2), sched
-
     if world == 1 and not args.no_secondary and args.workload == "k1000":
-        sec = {}
-        # ---- configs[1]: K = 100
-        obj, keep, sched = zero_shot_secondary(SECONDARY)
-        if not args.no_cpu_baseline:
-            obj["cpu_baseline"] = cpu_baseline(SECONDARY, sched, budget_s=60)
-        sec["k100"] = obj
-        del keep
-        torch.cuda.empty_cache()
-        # ---- configs[2]: Hard EM-Dirichlet at K = 397, then SOFT_KMEANS on the same tasks
-        obj, (ev2, table2, labels2, idx2), sched = zero_shot_secondary(K397_HARD, "HARD_EM_DIRICHLET", K397_HARD["iters"], 1, 2)
-        ev3 = Evaluator_zero_shot(device=dev, args=CfgNode(dict(ev2.args, name_method="SOFT_KMEANS", iter=20)), log_file=None)
-        e3, _, acc3, _ = run_steps(ev3, table2, labels2, idx2, 1, 2)
-        T, K3 = K397_HARD["tasks_per_batch"] * K397_HARD["batches_per_gpu"], K397_HARD["K"]
-        # algorithmic HBM bytes of one SOFT_KMEANS iteration: statistics (u, z in; w out), distances (w, z in; logits out),
-        # softmax (logits in; u out) = 4 B x (6 T Q K + 2 T K K)
-        skm_bytes = 20 * 4.0 * (6.0 * T * N_QUERY * K3 + 2.0 * T * K3 * K3)
-        skm_flop = 20 * 5.0 * T * N_QUERY * K3 * K3                  # distances 3 flop per (q, k, d), statistics 2
-        obj["soft_kmeans"] = {"value": 2 * T / e3, "unit": "tasks/s", "steps": 2, "warmup": 1, "ms_per_step": 1e3 * e3 / 2,
-                              "mean_accuracy": float(acc3),
-                              "roofline": {"bound": "hbm", "kernel": "whole SOFT_KMEANS step (k_mstats_rows, k_kmeans_logits_rows, k_softmax)",
-                                           "achieved": skm_bytes / (e3 / 2) / 1e9, "peak": PEAK_HBM_GBS, "unit": "GB/s",
-                                           "frac": skm_bytes / (e3 / 2) / 1e9 / PEAK_HBM_GBS, "traffic": None,
-                                           "algorithmic_bytes_per_step": skm_bytes,
-                                           "fp32_tflops_of_the_two_contractions": skm_flop / (e3 / 2) / 1e12,
-                                           "note": "sums rebuilt in torch's association order (no MFMA): L2-resident re-reads of the "
-                                                   "task's feature block, not HBM, bound this step"}}
-        if not args.no_cpu_baseline:
-            obj["cpu_baseline"] = cpu_baseline(K397_HARD, sched, budget_s=60)
-        sec["k397_hard"] = obj
-        del ev2, ev3, table2, labels2, idx2
-        torch.cuda.empty_cache()
-        # ---- configs[4]: visual embeddings -> probability features -> 4-shot few-shot EM-Dirichlet at K = 1000
-        from src.eval_few_shot import Evaluator_few_shot
-        from tclip_amd import features
-        w = FS_K1000
-        K4, D = w["K"], w["dim"]
-        gen = torch.Generator().manual_seed(2024)
-        text = torch.randn(K4, D, generator=gen)
-        text /= text.norm(dim=-1, keepdim=True)
-        lab_s = torch.arange(K4).repeat_interleave(w["support_rows_per_class"])
-        lab_q = torch.arange(K4).repeat_interleave(w["query_rows_per_class"])
-        vis_s = (text[lab_s] * FS_K1000["signal"] + torch.randn(len(lab_s), D, generator=gen)).to(dev)
-        vis_q = (text[lab_q] * FS_K1000["signal"] + torch.randn(len(lab_q), D, generator=gen)).to(dev)
-        text_d = text.to(dev)
-        n_tasks = w["tasks_per_batch"] * w["batches_per_gpu"]
-        cfg = CfgNode(iter=ITERS, iter_mm=ITER_MM, num_classes_test=K4, n_class=K4, n_query=N_QUERY, k_eff=5, T=30,
-                      use_softmax_feature=True, graph_matching=True, shots=w["shots"], number_tasks=n_tasks,
-                      batch_size=w["tasks_per_batch"], name_method="EM_DIRICHLET", used_test_set="test", tunable=False)
-        ev4 = Evaluator_few_shot(device=dev, args=cfg, log_file=None)
-        random.seed(2020); np.random.seed(2020); torch.manual_seed(2020)
-        idx4 = ev4.sample_indices(lab_s.numpy(), lab_q.numpy())
-
-        def fs_step():                                   # the front-end is part of the step
-            tab_s = features.probability_features(vis_s, text_d, 30.0)
-            tab_q = features.probability_features(vis_q, text_d, 30.0)
-            return ev4.evaluate_tasks(None, tab_s, lab_s, tab_q, lab_q, indices=idx4)
-
-        e4, prof4, res4, _ = timed(fs_step, 1, 2)
-        sched = ev4.last_method.mm_iters[0].tolist()
-        obj = {"workload": w["text"], "value": 2 * n_tasks / e4, "unit": "tasks/s", "steps": 2, "warmup": 1, "ms_per_step": 1e3 * e4 / 2,
-               "mean_accuracy": float(res4[0]), "mm_iters_batch0": sched, "roofline": roofline_of(prof4, 2, K4, w["name"]),
-               "support_rows_per_task": K4 * w["shots"],
-               "note": "few-shot has no dead rows: all K rows of every task iterate in every outer iteration "
-                       "(roofline.element_updates_executed_per_step counts them)"}
-        if not args.no_cpu_baseline:
-            obj["cpu_baseline"] = cpu_baseline(w, sched, budget_s=90)
-        sec["fs_k1000"] = obj
-        del ev4, vis_s, vis_q
-        torch.cuda.empty_cache()
-        line["secondary"] = dict(sec["k100"], **{k: v for k, v in sec.items()})
+        sec = {name: fn() for name, fn in runners.items()}
+        line["secondary"] = dict(sec["k100"], **sec)
 
     if rank == 0:
         if world == 1 and not args.no_cpu_baseline:

@@ -1,5 +1,6 @@
 #!/bin/bash
-# rocprofv3 kernel-trace + stats of one bench step (the K=1000 headline; pass "k100" for the secondary workload)
+# rocprofv3 kernel-trace + stats of one bench step: scripts/gpu_prof_bench.sh [k1000|k100|k397_hard|fs_k1000]
+# (k1000: the headline; the others: that workload alone).  Writes gpurun_out/prof_bench_<w>.{kernel_stats.csv,kernel_trace_head.csv,bench.json}
 cd /tmp && export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT
 W=${1:-k1000}
@@ -7,7 +8,7 @@ OUT=$R/gpurun_out/prof_bench_$W
 timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT -- python3 $R/bench.py --workload $W --steps 1 --warmup 1 --no-cpu-baseline --no-secondary 2>&1 | tail -1 > $OUT.bench.json
 find $OUT -name "*kernel_stats.csv" | head -1 | xargs -I{} cp {} $OUT.kernel_stats.csv
 f=$(find $OUT -name "*kernel_trace.csv" | head -1)
-head -1 $f > $OUT.kernel_trace_head.csv; grep -m 3 "k_mm_live<.*false" $f >> $OUT.kernel_trace_head.csv
+head -1 $f > $OUT.kernel_trace_head.csv; grep -m 3 "k_mm_live<.*false" $f >> $OUT.kernel_trace_head.csv; grep -m 3 "k_mm_split<" $f >> $OUT.kernel_trace_head.csv
 rm -rf $OUT
 python3 - $OUT.kernel_stats.csv <<'PY'
 import csv,sys
