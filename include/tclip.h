@@ -25,7 +25,9 @@
 extern "C" {
 #endif
 
-#define TCLIP_ABI_VERSION 1
+/* 2: tclip_alpha_tim_run, tclip_laplacian_shot_run, tclip_match_clusters_host_strided, tclip_debug_set_mm_split added
+ * (every version-1 entry point keeps its signature) */
+#define TCLIP_ABI_VERSION 2
 
 enum {
     TCLIP_OK = 0,

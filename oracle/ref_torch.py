@@ -75,7 +75,8 @@ def run(x_q, x_s=None, y_s=None, *, n_class, iters, iter_mm=1000, lambd, hard=Fa
     """Runs the loop on CPU.  x_q (N,Q,K) probability features; x_s/y_s given = few-shot.
 
     lambd is the reference's integer `int(K/5)*n_query` (zero-shot) or `int(K/k_eff)*n_query`.
-    Returns dict(u, v, alpha, criterions (iters,), mm_iters list, seconds).
+    Returns dict(u, v, alpha, criterions (iters,), mm_iters list, seconds, seconds_mm / seconds_iter: host wall time of
+    every outer iteration's MM loop and of the whole outer iteration - what bench.py's cpu_baseline extrapolates from).
     `trace`, if a dict, receives per-iteration 'argmax' and 'live' lists.
     """
     few = x_s is not None
@@ -94,21 +95,29 @@ def run(x_q, x_s=None, y_s=None, *, n_class, iters, iter_mm=1000, lambd, hard=Fa
         support.add_(EPS).log_()
         query.add_(EPS).log_()          # few-shot works on log-features from here on
         log_q = query
-    criterions, mm_iters = [], []
+    criterions, mm_iters, seconds_mm, seconds_iter = [], [], [], []
     t0 = time.time()
+    _mm_solve = mm_solve
+
+    def mm_solve_timed(*a):
+        t = time.time()
+        r = _mm_solve(*a)
+        seconds_mm.append(time.time() - t)
+        return r
     for _ in range(iters):
+        t_iter = time.time()
         if few:
             denom = (1 / (ys_hot.sum(dim=1) + u.sum(dim=1))).unsqueeze(-1)
             y_cst = denom * ((ys_hot.unsqueeze(-1) * support.unsqueeze(2)).sum(dim=1)
                              + (u.unsqueeze(-1) * log_q.unsqueeze(2)).sum(dim=1))
-            alpha, n_mm = mm_solve(alpha, y_cst, iter_mm, pi2_6, lgamma_1)
+            alpha, n_mm = mm_solve_timed(alpha, y_cst, iter_mm, pi2_6, lgamma_1)
         else:
             sizes = u.sum(dim=1).unsqueeze(-1).float()
             live = sizes > EPS
             y_cst = ((u.unsqueeze(-1) * torch.log(query + EPS).unsqueeze(2)).sum(1)
                      / u.sum(1).clamp(min=EPS).unsqueeze(-1))
             y_cst = y_cst * live + (1 - 1 * live) * torch.ones_like(y_cst) * (-10)
-            alpha, n_mm = mm_solve(alpha, y_cst, iter_mm, pi2_6, lgamma_1)
+            alpha, n_mm = mm_solve_timed(alpha, y_cst, iter_mm, pi2_6, lgamma_1)
             alpha = alpha * live + alpha_old * (1 - 1 * live)
             if trace is not None:
                 trace.setdefault("live", []).append(live.squeeze(-1).clone())
@@ -130,8 +139,9 @@ def run(x_q, x_s=None, y_s=None, *, n_class, iters, iter_mm=1000, lambd, hard=Fa
             # alpha_old was refreshed, so what it logs is identically 0.
             crit = ((alpha_old - alpha).norm(dim=(1, 2)) / alpha_old.norm(dim=(1, 2))).mean(0)
         criterions.append(crit)
+        seconds_iter.append(time.time() - t_iter)
     return {"u": u, "v": v, "alpha": alpha, "criterions": torch.stack(criterions),
-            "mm_iters": mm_iters, "seconds": time.time() - t0}
+            "mm_iters": mm_iters, "seconds": time.time() - t0, "seconds_mm": seconds_mm, "seconds_iter": seconds_iter}
 
 
 def clustering_accuracy(u, x_q, y_q, n_class, graph_matching=True):

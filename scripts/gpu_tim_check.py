@@ -25,6 +25,20 @@ for path in sorted(glob.glob(os.path.join(ROOT, "tests", "golden", "fs_tim_*.npz
           f"crit rel {np.abs(crit[0].cpu().numpy() / g['criterions'] - 1).max():.2e}  "
           f"pred mismatches {(preds.cpu().numpy() != g['logits_q'].argmax(2)).sum()}  acc equal {np.array_equal(acc.numpy(), g['acc'][:, 0])}")
 
+for path in sorted(glob.glob(os.path.join(ROOT, "tests", "golden", "fs_lshot_*.npz"))):
+    g = np.load(path)
+    unary, nbr, preds_iter, e = engine.run_laplacian_shot(
+        torch.from_numpy(g["x_q"]).cuda(), torch.from_numpy(g["x_s"]).cuda(), torch.from_numpy(g["y_s"]).squeeze(2).cuda(),
+        iters=int(g["iters"]), knn=int(g["knn"]), lmd=float(g["lmd"]), norm_type=str(g["norm_type"]))
+    torch.cuda.synchronize()
+    ref_u = g["unary"]
+    du = np.abs(unary.cpu().numpy() - ref_u) / np.maximum(np.abs(ref_u), 1e-30)
+    ee = e.cpu().numpy().reshape(g["ent_energy"].shape)
+    de = np.abs(ee / g["ent_energy"] - 1)
+    print(f"{os.path.basename(path)[:-4]:28s} unary rel {du.max():.2e}  energy rel {np.nanmax(de):.2e}  "
+          f"neighbours equal {np.array_equal(np.sort(nbr.cpu().numpy(), axis=2), g['neighbours'])}  "
+          f"preds equal {np.array_equal(preds_iter[:, -1].cpu().numpy(), g['preds'])}")
+
 for K, N, shots, iters in ((100, 100, 4, 1000), (10, 100, 4, 1000), (397, 20, 4, 1000), (1000, 4, 4, 100)):
     x_q, _ = synth.make_query_tasks(N, K, seed=5, k_eff=5)
     x_s, y_s = synth.make_support(N, K, shots, seed=5)

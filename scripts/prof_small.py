@@ -11,6 +11,9 @@ iters = int(sys.argv[4]) if len(sys.argv) > 4 else 3
 hard = bool(int(sys.argv[5])) if len(sys.argv) > 5 else False
 if os.environ.get('TCLIP_WIDE'):
     engine.debug_set_rowset_min_rows(0)          # 32 lanes per row for every K (test hook)
+if os.environ.get('TCLIP_SPLIT_MODE'):
+    from tclip_amd import _capi
+    _capi.lib().tclip_debug_set_mm_split(int(os.environ['TCLIP_SPLIT_MODE']))      # 0: k_mm_live everywhere (the round-2 path)
 x_q, y_q = synth.make_query_tasks(B * N, K, seed=3)
 x_q = x_q.cuda()
 for rep in range(2):

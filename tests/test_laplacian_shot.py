@@ -2,7 +2,9 @@
 the removed alias `np.float` restored for that process - tests/golden/make_golden_lshot.py), and the HIP path against
 the same vectors (GPU).  The reference's host code (numpy pairwise sums and exp, sklearn's distance kernels) is not
 reproduced bit for bit: the neighbour lists, every per-update accuracy and the final assignment must be EQUAL, the unary
-term agrees to 1e-5 relative and the bound energies to 1e-6 relative."""
+term and the bound energies agree within per-fixture bounds at twice the deviation measured on MI355X
+(tests/golden/f4_tolerances.json: unary <= 1.3e-6 relative, energies <= 2.3e-7 relative)."""
+import json
 import os
 
 import numpy as np
@@ -13,6 +15,7 @@ from conftest import GOLDEN, golden_names
 from oracle import ref_torch
 
 NAMES = golden_names("fs_lshot_")
+BOUNDS = json.load(open(os.path.join(GOLDEN, "f4_tolerances.json")))["laplacian_shot"]
 
 
 def test_fixtures_present():
@@ -44,11 +47,14 @@ def test_engine_matches_reference(name):
     logs = m.run_task(task_dic={"x_q": torch.from_numpy(g["x_q"]), "y_q": torch.from_numpy(g["y_q"]),
                                 "x_s": torch.from_numpy(g["x_s"]), "y_s": torch.from_numpy(g["y_s"])}, shot=int(g["shots"]))
     assert np.array_equal(np.sort(m.neighbours.cpu().numpy(), axis=2), g["neighbours"]), "kNN graph differs"
-    assert np.allclose(m.unary.cpu().numpy(), g["unary"], rtol=1e-5, atol=1e-9), "unary term differs"
+    b = BOUNDS[name]                                   # twice the deviation measured on MI355X (tests/golden/f4_tolerances.json)
+    du = np.abs(m.unary.cpu().numpy() - g["unary"]) / np.maximum(np.abs(g["unary"]), 1e-30)
+    assert du.max() <= b["unary_rel"], f"unary term differs by {du.max():.2e} relative (bound {b['unary_rel']:.1e})"
     assert np.array_equal(m.preds.cpu().numpy(), g["preds"]), "final assignment differs"
     assert logs["acc"].shape == g["acc"].shape and np.array_equal(logs["acc"], g["acc"]), "per-update accuracies differ"
     assert logs["ent_energy"].shape == g["ent_energy"].shape
-    assert np.allclose(logs["ent_energy"], g["ent_energy"], rtol=1e-6, atol=0), np.abs(logs["ent_energy"] / g["ent_energy"] - 1).max()
+    de = np.abs(np.asarray(logs["ent_energy"]) / g["ent_energy"] - 1).max()
+    assert de <= b["energy_rel"], f"energies differ by {de:.2e} relative (bound {b['energy_rel']:.1e})"
     assert logs["criterions"] == [[0]] * N
 
 

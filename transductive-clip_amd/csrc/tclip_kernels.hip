@@ -918,6 +918,12 @@ __global__ __launch_bounds__(64 * W, (E > 16 ? TCLIP_MM_WAVES_LARGE : TCLIP_MM_W
 #define TCLIP_SPLIT_MAX_E 24       // two words of LDS per element: 8 KB per wavefront at 16 registers per lane (16 wavefronts per CU),
                                    // 12 KB at 24 (12 wavefronts per CU, which is what those kernels' registers allow anyway)
 #endif
+#ifndef TCLIP_SPLIT_WAVES_SMALL
+#define TCLIP_SPLIT_WAVES_SMALL 4  // wavefronts per SIMD requested for up to 8 registers per lane
+#endif
+#ifndef TCLIP_SPLIT_WAVES_MID
+#define TCLIP_SPLIT_WAVES_MID 4    // wavefronts per SIMD requested for 9..16 registers per lane
+#endif
 #ifndef TCLIP_SPLIT_MIN_E
 #define TCLIP_SPLIT_MIN_E 5        // shorter rows fill too little of a dense pass: measured with 16 lanes per row on 1000 tasks,
                                    // split against k_mm_live: K = 10 +42 %, 37 +6 %, 47 +7 %, 64 +1 %, 80 -4.5 %, 96 -5 %, 100 -11 %,
@@ -1122,7 +1128,7 @@ __device__ __forceinline__ void mm_iterate_wave_split(float (&beta)[E], const Ro
 }
 
 template <int E, int G>
-__global__ __launch_bounds__(64, (E > 16 ? TCLIP_MM_WAVES_LARGE : TCLIP_MM_WAVES_SMALL)) void k_mm_split(MMArgs a) {
+__global__ __launch_bounds__(64, (E > 16 ? TCLIP_MM_WAVES_LARGE : (E > 8 ? TCLIP_SPLIT_WAVES_MID : TCLIP_SPLIT_WAVES_SMALL))) void k_mm_split(MMArgs a) {
     static_assert(E <= TCLIP_SPLIT_MAX_E, "LDS: two words per element");
     __shared__ LogTabEntry tab[16];
     __shared__ float plane0[64 * E];

@@ -87,7 +87,8 @@ def parse_args(argv=None):
     return ns, cfg
 
 
-def main(argv=None):
+def main(argv=None, keep_process_group=False):
+    """keep_process_group: a caller that runs several evaluations in one process (sweep.py) destroys the group itself"""
     ns, args = parse_args(argv)
     dist_on = "RANK" in os.environ
     local_rank = int(os.environ.get("LOCAL_RANK", args.device))
@@ -99,7 +100,8 @@ def main(argv=None):
     device = torch.device("cuda", local_rank)
     if dist_on:
         import torch.distributed as dist
-        dist.init_process_group("nccl", device_id=device)
+        if not dist.is_initialized():          # sweep.py calls main() repeatedly in one process: the group is created once
+            dist.init_process_group("nccl", device_id=device)
     if ns.support is not None and ns.query is None:
         raise SystemExit("--support needs --query (or give neither and use the data/<dataset>/saved_features/ layout)")
     query_path = ns.query or reporting.saved_feature_path(args, args.used_test_set, ns.results_root)
@@ -130,7 +132,8 @@ def main(argv=None):
     if dist_on:
         import torch.distributed as dist
         dist.barrier()
-        dist.destroy_process_group()
+        if keep_process_group is False:
+            dist.destroy_process_group()
     return acc, t, path
 
 

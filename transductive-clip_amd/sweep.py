@@ -70,13 +70,19 @@ def main(argv=None):
                ["--opts"] + opts + list(ns.opts)
         label = " ".join(opts)
         try:
-            acc, t, path = main_features.main(args)
-        except SystemExit as e:                      # missing feature files, bad options: report and go on
+            acc, t, path = main_features.main(args, keep_process_group=True)
+        except SystemExit as e:                      # missing feature files, bad options: report and go on (every rank takes the same exit)
             print(f"[skipped] {label}: {e}", flush=True)
             table.append((label, None))
             continue
+        if acc is None:                              # under torch.distributed.run only rank 0 holds the gathered result
+            continue
         table.append((label, float(acc)))
         print(f"[done] {label}: {100 * float(acc):.2f} %", flush=True)
+    if "RANK" in os.environ:
+        import torch.distributed as dist
+        if dist.is_initialized():
+            dist.destroy_process_group()
     return table
 
 

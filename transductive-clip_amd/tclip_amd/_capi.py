@@ -80,7 +80,7 @@ def lib():
         for name, (res, args) in _SIGNATURES.items():
             fn = getattr(l, name)
             fn.restype, fn.argtypes = res, args
-        if l.tclip_abi_version() != 1:
+        if l.tclip_abi_version() != 2:
             raise RuntimeError("libtclip.so ABI version mismatch")
         _lib = l
     return _lib
