@@ -1100,6 +1100,8 @@ __device__ __forceinline__ void mm_iterate_wave_split(float (&beta)[E], const Ro
         if (ok0) { my0[i0] = lg.x; my1[i0] = psi.x; }
         if (ok1) { my0[i1] = lg.y; my1[i1] = psi.y; }
     }
+    // (two entries per lane in these passes - two independent chains for the scheduler to interleave - measured no
+    // different: K = 100 361 against 359 ms, K = 1000 equal; the passes are not latency-bound)
     for (int j = 0; j < nB; j += 64) {
         const int i = nA + j + lane64;
         const bool ok = j + lane64 < nB;
