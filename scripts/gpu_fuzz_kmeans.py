@@ -4,8 +4,8 @@ bit for bit when the host's torch runs the AVX-512 kernels with at most 8 thread
 PADDLE go through torch.log = MKL vsLn on the host side, whose kernel choice differs between hosts
 (the GPU pool's host does not reproduce the fixture host's logs), so they are compared to 1e-4 here;
 their bit-exactness is pinned by the fixtures the reference produced on the fixture host and by
-scripts/gpu_dump_kmeans.py + scripts/check_kmeans_dump.py (digests of the engine's outputs, compared on the
-fixture host: exact).  EM_GAUSSIAN_COV multiplies by inverse variances of up to 2e15, so a 1-ulp
+tests/test_gpu_digests_kmeans.py (digests of the torch-eager restatement made on the fixture host, tests/golden/digests_kmeans.json,
+on platform-independent inputs: exact).  EM_GAUSSIAN_COV multiplies by inverse variances of up to 2e15, so a 1-ulp
 difference of the host's log can exceed the tolerance: its column is printed but not counted."""
 import os, random, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))

@@ -1082,7 +1082,9 @@ __device__ __forceinline__ void mm_iterate_wave_split(float (&beta)[E], const Ro
     }
     const float psi_s = digamma_pos_f32(s, tab);                    // the row sums of the wavefront's rows, one evaluation
     // phase B: the queues in dense passes; entry i leaves with lgamma(a+1) in plane 0 and digamma(a+1) in plane 1
-    for (int j = 0; j < nA; j += 128) {
+    int jA = 0;
+    for (; jA + 64 < nA; jA += 128) {                               // more than 64 entries left: two per lane on the packed pipe
+        const int j = jA;
         const int i0 = j + lane64, i1 = i0 + 64;
         const bool ok0 = i0 < nA, ok1 = i1 < nA;
         const f2 x{ok0 ? my0[i0] : 1.5f, ok1 ? my0[i1] : 1.5f};
@@ -1100,15 +1102,32 @@ __device__ __forceinline__ void mm_iterate_wave_split(float (&beta)[E], const Ro
         if (ok0) { my0[i0] = lg.x; my1[i0] = psi.x; }
         if (ok1) { my0[i1] = lg.y; my1[i1] = psi.y; }
     }
+    for (; jA < nA; jA += 64) {                                     // a last pass of up to 64 entries: one per lane (half the instructions)
+        const int i = jA + lane64;
+        const bool ok = i < nA;
+        const float x = ok ? my0[i] : 1.5f;
+        float xr = x, acc = 0.0f;
+#pragma unroll
+        for (int k = 0; k < 8; k++) {
+            acc = acc - rcp_rn_f32(xr);
+            xr = xr + 1.0f;
+        }
+        const float m = below10_f32(xr);
+        acc = __builtin_fmaf(-m, rcp_rn_f32(xr), acc);
+        xr = xr + m;
+        const float psi = digamma_after_rec(xr, acc, tab);
+        bool sure;
+        float lg = lgamma_sleef_1_23_f64(x, sure);
+        if (__builtin_expect(__builtin_amdgcn_ballot_w64(!sure) != 0ull, 0)) lg = sure ? lg : lgamma_sleef_05_23(x);
+        if (ok) { my0[i] = lg; my1[i] = psi; }
+    }
     // (two entries per lane in these passes - two independent chains for the scheduler to interleave - measured no
     // different: K = 100 361 against 359 ms, K = 1000 equal; the passes are not latency-bound)
-    for (int j = 0; j < nB; j += 64) {
-        const int i = nA + j + lane64;
-        const bool ok = j + lane64 < nB;
+    auto pass_b = [&](int i, bool ok) {                            // recurrence (eight masked steps: x + 8 >= 10) + series + general large-argument lgamma
         const float x = ok ? my0[i] : 5.0f;
         float xr = x, acc = 0.0f;
 #pragma unroll
-        for (int k = 0; k < 8; k++) {                               // x + 8 >= 10: a ninth step is never taken
+        for (int k = 0; k < 8; k++) {
             const float m = below10_f32(xr);
             acc = __builtin_fmaf(-m, rcp_rn_f32(xr), acc);
             xr += m;
@@ -1116,8 +1135,19 @@ __device__ __forceinline__ void mm_iterate_wave_split(float (&beta)[E], const Ro
         const float psi = digamma_after_rec(xr, acc, tab);
         const float lg = lgamma_big_dense(x);
         if (ok) { my0[i] = lg; my1[i] = psi; }
+    };
+    // When the last, partial passes of B and C fit into one (<= 64 entries together), class C's leftovers ride in B's pass:
+    // the masked recurrence takes no step from 10 on and the general lgamma returns what the no-shift form returns (both are
+    // RN32 of Sleef's value), so the entries get the same bits for the price of one pass instead of two.
+    const int tB = nB & 63, tC = nC & 63;
+    const bool merged = tB > 0 && tC > 0 && tB + tC <= 64;
+    const int endB = merged ? nB - tB : nB, endC = merged ? nC - tC : nC;
+    for (int j = 0; j < endB; j += 64) pass_b(nA + j + lane64, j + lane64 < nB);
+    if (merged) {
+        const bool fromB = lane64 < tB;
+        pass_b(fromB ? nA + endB + lane64 : nA + nB + endC + (lane64 - tB), lane64 < tB + tC);
     }
-    for (int j = 0; j < nC; j += 64) {
+    for (int j = 0; j < endC; j += 64) {
         const int i = nA + nB + j + lane64;
         const bool ok = j + lane64 < nC;
         const float x = ok ? my0[i] : 16.0f;
