@@ -438,9 +438,9 @@ __device__ __forceinline__ int full_registers(int K) {
     else return K / G;
 }
 
-template <int E, int G = kGroup>
+template <int E, int G = kGroup, int kRegsMaxE = TCLIP_Y_REGS_MAX_E>
 struct RowY {
-    static constexpr bool kInRegs = E <= TCLIP_Y_REGS_MAX_E;
+    static constexpr bool kInRegs = E <= kRegsMaxE;
     float r[kInRegs ? E : 1];
     const float* g;      // row base in global memory, or nullptr for a dead row (y = -10)
     int lane, K, n_full; // n_full = K / 32: registers below it lie entirely inside the row (wave-uniform)
@@ -918,6 +918,9 @@ __global__ __launch_bounds__(64 * W, (E > 16 ? TCLIP_MM_WAVES_LARGE : TCLIP_MM_W
 #define TCLIP_SPLIT_MAX_E 24       // two words of LDS per element: 8 KB per wavefront at 16 registers per lane (16 wavefronts per CU),
                                    // 12 KB at 24 (12 wavefronts per CU, which is what those kernels' registers allow anyway)
 #endif
+#ifndef TCLIP_SPLIT_Y_REGS_MAX_E
+#define TCLIP_SPLIT_Y_REGS_MAX_E TCLIP_Y_REGS_MAX_E   // y of a row in registers up to this many registers per lane (else re-read from L1/L2 in phase C)
+#endif
 #ifndef TCLIP_SPLIT_WAVES_SMALL
 #define TCLIP_SPLIT_WAVES_SMALL 4  // wavefronts per SIMD requested for up to 8 registers per lane
 #endif
@@ -940,7 +943,7 @@ __device__ __forceinline__ float lgamma_gt7_dense(float v) {
 
 // phase C of the split iteration: entry `slot` of the wavefront's planes holds lgamma(a+1) and digamma(a+1)
 template <int E, int G>
-__device__ __forceinline__ void split_apply_updates(float (&beta)[E], const RowY<E, G>& yv, int K, int lane, float psi_s,
+__device__ __forceinline__ void split_apply_updates(float (&beta)[E], const RowY<E, G, TCLIP_SPLIT_Y_REGS_MAX_E>& yv, int K, int lane, float psi_s,
                                                     const float* my0, const float* my1, const uint32_t (&slot)[(E + 1) / 2],
                                                     bool measure, double& num, double& den) {
     const int n_full = full_registers<E, G>(K);
@@ -992,7 +995,7 @@ __device__ __forceinline__ void split_apply_updates(float (&beta)[E], const RowY
 
 // my0 / my1: the wavefront's two planes of 64 E words
 template <int E, int G>
-__device__ __forceinline__ void mm_iterate_wave_split(float (&beta)[E], const RowY<E, G>& yv, int K, int lane, bool active,
+__device__ __forceinline__ void mm_iterate_wave_split(float (&beta)[E], const RowY<E, G, TCLIP_SPLIT_Y_REGS_MAX_E>& yv, int K, int lane, bool active,
                                                       const LogTabEntry* tab, float* my0, float* my1, bool measure,
                                                       double& num, double& den) {
     const int lane64 = threadIdx.x & 63;
@@ -1177,7 +1180,7 @@ __global__ __launch_bounds__(64, (E > 16 ? TCLIP_MM_WAVES_LARGE : (E > 8 ? TCLIP
         const bool active = i < n && !a.stop[row / a.rows_per_batch];
         if (!__any(active)) continue;
         float beta[E];
-        RowY<E, G> yv;
+        RowY<E, G, TCLIP_SPLIT_Y_REGS_MAX_E> yv;
         double num = 0.0, den = 0.0;
         yv.load(a.y + (size_t)row * K, lane, K);
 #pragma unroll
