@@ -53,9 +53,11 @@ __device__ __forceinline__ double group_shfl_xor(double v, int m) { return __shf
 // value in all 32 lanes of the group.
 // kLane0: the caller needs the sum in lane 0 of the group only (the last eight additions then take their operands
 // through DPP instead of eight LDS-crossbar shuffles).
-template <int E, bool kLane0 = false>
+// kFullRegs: the caller guarantees K >= 32 kFullRegs (registers below that index lie inside the row for every K the
+// instantiation is used for), which frees their additions from the per-register tests.
+template <int E, bool kLane0 = false, int kFullRegs = 0>
 __device__ __forceinline__ float group_sum_torch(const float (&x)[E], int K, int lane) {
-    if (K < 8) {  // scalar_inner_sum: 4 interleaved scalar accumulators
+    if (kFullRegs == 0 && K < 8) {  // scalar_inner_sum: 4 interleaved scalar accumulators
         const int size_ilp = K >> 2;
         float fin = size_ilp ? group_shfl(x[0], 0) : 0.0f;
         for (int i = size_ilp * 4; i < K; i++) fin += group_shfl(x[0], i);
@@ -71,9 +73,13 @@ __device__ __forceinline__ float group_sum_torch(const float (&x)[E], int K, int
     float a0 = 0.0f, a1 = 0.0f, ragged = 0.0f;
 #pragma unroll
     for (int e = 0; e < E; e++) {
-        if (e == 16 && size_ilp >= 16) { a1 += a0; a0 = 0.0f; }
-        if (e < size_ilp) a0 += x[e];
-        if (e == size_ilp) ragged = x[e];
+        if (e == 16 && (kFullRegs >= 16 || size_ilp >= 16)) { a1 += a0; a0 = 0.0f; }
+        if (e < kFullRegs) {
+            a0 += x[e];
+        } else {
+            if (e < size_ilp) a0 += x[e];
+            if (e == size_ilp) ragged = x[e];
+        }
     }
     if (E == 32 && size_ilp >= 32) { a1 += a0; a0 = 0.0f; }
     const float pm = a0 + a1;                       // per-(accumulator, lane) partial

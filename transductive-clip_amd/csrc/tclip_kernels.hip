@@ -1330,40 +1330,84 @@ __global__ __launch_bounds__(256) void k_row_consts(const float* __restrict__ al
 }
 
 // E-step, part 2: logit0[t,q,k] = rowc[t,k] + sum_d (alpha[t,k,d]-1) * logz[t,q,d]   (em_dirichlet.py:37-39)
-// One block per row; its 8 groups sweep the queries with the alpha row held in registers.
-template <int E>
+// A block takes R consecutive entries of the row list (neighbours in the list are rows of one task almost always:
+// k_build_rows keeps 64-row spans together) with their alpha in registers; its 8 lane groups sweep the task's queries,
+// each log z row loaded once for the R rows.  Blocks b, b + 8, b + 16, ... (one XCD under round-robin dispatch) walk ONE
+// contiguous eighth of the list, so that a task's 75 K log z values are pulled into one L2 instead of eight.
+// Registers below index logits_full_regs(E) lie inside the row for every K that dispatch_E hands to the instantiation
+// (K > 32 x the next smaller size): their loads, products and additions carry no bounds tests.
+constexpr int logits_full_regs(int E) {
+    constexpr int sizes[] = {0, 1, 2, 3, 4, 6, 8, 10, 13, 16, 20, 24, 28, 32};      // dispatch_E's
+    int prev = 0;
+    for (int s : sizes) {
+        if (s >= E) break;
+        prev = s;
+    }
+    return prev;
+}
+template <int E, int R>
 __global__ __launch_bounds__(256) void k_logits(const float* __restrict__ alpha, const float* __restrict__ logz,
                                                 const float* __restrict__ rowc, const int32_t* __restrict__ rows,
                                                 const int32_t* __restrict__ n_rows, int Q, int K,
                                                 float* __restrict__ logit0, const int32_t* __restrict__ only_if) {
     if (only_if && *only_if == 0) return;           // the initial call: k_init_logits has done the work
+    constexpr int kFull = logits_full_regs(E);
+    constexpr int kGroups = 256 / kGroup;
     const int lane = threadIdx.x & (kGroup - 1);
-    const int group = threadIdx.x / kGroup, groups_per_block = blockDim.x / kGroup;
+    const int group = threadIdx.x / kGroup;
     const int n = *n_rows;
-    for (int i = blockIdx.x; i < n; i += gridDim.x) {
-        const int row = rows[i];
-        const int t = row / K, k = row % K;
-        float am1[E];
+    const int nseg = (n + R - 1) / R, per_xcd = (nseg + 7) >> 3;
+    const int xcd = blockIdx.x & 7;
+    for (int j = blockIdx.x >> 3; j < per_xcd; j += gridDim.x >> 3) {              // the grid is a multiple of 8 blocks
+        const int seg = xcd * per_xcd + j;
+        if (seg >= nseg) break;
+        int row[R], task[R];
+        bool same = true;
+        float am1[R][E], rc[R];
 #pragma unroll
-        for (int e = 0; e < E; e++) {
-            const int d = e * kGroup + lane;
-            am1[e] = d < K ? alpha[(size_t)row * K + d] - 1.0f : 0.0f;
-        }
-        const float rc = rowc[row];
-        for (int q = group; q < Q; q += groups_per_block) {
-            const float* lz = logz + ((size_t)t * Q + q) * K;
-            // every load unconditional (index clamped into the row) so that they form one batch in flight; the select
-            // comes afterwards
-            float lv[E], pr[E];
+        for (int r = 0; r < R; r++) {
+            // (a segment past the end of the list repeats its first row: same value to the same place)
+            row[r] = __builtin_amdgcn_readfirstlane(rows[seg * R + r < n ? seg * R + r : seg * R]);
+            task[r] = row[r] / K;
+            same = same && task[r] == task[0];
+            const float* ar = alpha + (size_t)row[r] * K + lane;
 #pragma unroll
             for (int e = 0; e < E; e++) {
-                const int d = e * kGroup + lane;
-                lv[e] = lz[d < K ? d : K - 1];
+                if (e < kFull) am1[r][e] = ar[e * kGroup] - 1.0f;
+                else am1[r][e] = e * kGroup + lane < K ? ar[e * kGroup] - 1.0f : 0.0f;
             }
+            rc[r] = rowc[row[r]];
+        }
+        auto sweep = [&](int t, auto&& use) {        // the task's queries: log z row q in registers, handed to use(q, lv)
+            for (int q = group; q < Q; q += kGroups) {
+                const float* lz = logz + ((size_t)t * Q + q) * K + lane;
+                float lv[E];
 #pragma unroll
-            for (int e = 0; e < E; e++) pr[e] = e * kGroup + lane < K ? am1[e] * lv[e] : 0.0f;
-            const float l3 = group_sum_torch<E>(pr, K, lane);
-            if (lane == 0) logit0[((size_t)t * Q + q) * K + k] = rc + l3;
+                for (int e = 0; e < E; e++) {
+                    if (e < kFull) lv[e] = lz[e * kGroup];
+                    else lv[e] = lz[e * kGroup + lane < K ? e * kGroup : K - 1 - lane];   // clamped into the row: the load is unconditional
+                }
+                use(q, lv);
+            }
+        };
+        auto one = [&](int r, int t, int q, const float (&lv)[E]) {
+            float pr[E];
+#pragma unroll
+            for (int e = 0; e < E; e++) {
+                pr[e] = am1[r][e] * lv[e];
+                if (e >= kFull) pr[e] = e * kGroup + lane < K ? pr[e] : 0.0f;
+            }
+            const float l3 = group_sum_torch<E, true, kFull>(pr, K, lane);
+            if (lane == 0) logit0[((size_t)t * Q + q) * K + (row[r] - t * K)] = rc[r] + l3;
+        };
+        if (same) {
+            sweep(task[0], [&](int q, const float (&lv)[E]) {
+#pragma unroll
+                for (int r = 0; r < R; r++) one(r, task[0], q, lv);
+            });
+        } else {                                     // the segment straddles two tasks
+#pragma unroll
+            for (int r = 0; r < R; r++) sweep(task[r], [&](int q, const float (&lv)[E]) { one(r, task[r], q, lv); });
         }
     }
 }
@@ -2274,7 +2318,9 @@ template <int E> struct LaunchRowConsts {
 template <int E> struct LaunchLogits {
     static void run(int grid, hipStream_t st, const float* alpha, const float* logz, const float* rowc,
                     const int32_t* rows, const int32_t* n, int Q, int K, float* logit0, const int32_t* only_if) {
-        hipLaunchKernelGGL(k_logits<E>, dim3(grid), dim3(256), 0, st, alpha, logz, rowc, rows, n, Q, K, logit0, only_if);
+        constexpr int kRows = E <= 16 ? 4 : 2;                       // registers: kRows x E for the rows' alpha
+        hipLaunchKernelGGL((k_logits<E, kRows>), dim3((grid + 7) / 8 * 8), dim3(256), 0, st, alpha, logz, rowc, rows, n, Q, K, logit0,
+                           only_if);
     }
 };
 
