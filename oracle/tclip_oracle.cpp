@@ -173,8 +173,12 @@ static inline uint64_t row_hash(const float* x, int K) {
     }
     return h;
 }
+// Second design-study hook (scripts/stationary_elements.py): g_same_out[(it * iter_mm + l) * 2] = number of elements of live
+// rows that MM iteration l of outer iteration `it` left bitwise unchanged, [+1] = number of elements of live rows.
+static int64_t* g_same_out = nullptr;
 extern "C" {
 void tclip_oracle_set_cycle_probe(int32_t* out, int max_period) { g_cycle_out = out; g_cycle_max_period = max_period; }
+void tclip_oracle_set_stationary_probe(int64_t* out) { g_same_out = out; }
 
 // Runs the whole loop for ONE reference batch of n_task tasks.
 //   z        [N,Q,K] probability features (query)
@@ -265,6 +269,16 @@ int tclip_oracle_run(const float* z, const float* xs, const int64_t* ys, int N, 
                         }
                     ring[(size_t)row * P + (l + 1) % P] = h;
                 }
+            }
+            if (g_same_out) {
+                int64_t same = 0, total = 0;
+                for (long row = 0; row < (long)N * K; row++) {
+                    if (!(few || live[row])) continue;
+                    total += K;
+                    for (int d = 0; d < K; d++) same += memcmp(&next[row * K + d], &beta[row * K + d], 4) == 0;
+                }
+                g_same_out[((size_t)it * iter_mm + l) * 2] = same;
+                g_same_out[((size_t)it * iter_mm + l) * 2 + 1] = total;
             }
             executed++;
             result_in_next = true;

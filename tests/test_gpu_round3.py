@@ -163,3 +163,25 @@ def test_class_split_kernel_with_nan_and_stopped_batches():
         for name in ("alpha", "u", "v", "preds", "mm_iters"):
             x, y = getattr(a, name), getattr(b, name)
             assert torch.equal(torch.nan_to_num(x.float(), nan=-7.0), torch.nan_to_num(y.float(), nan=-7.0)), name
+
+
+# dispatch_E's register counts for the 32-lane E-step kernels: k_logits<E, R> drops the bounds tests on registers below the next
+# smaller count (K > 32 x that count for every K the instantiation sees), so the first and the last K of every bucket are the cases
+@pytest.mark.parametrize("K", [32, 33, 64, 65, 96, 97, 128, 129, 192, 193, 256, 257, 320, 321, 416, 417, 512, 513, 640, 641,
+                               768, 769, 896, 897])
+def test_e_step_at_the_edges_of_every_row_width_bucket(K):
+    """k_row_consts / k_logits at the first and last row length of each instantiation, three tasks (the row list's segments of
+    2 or 4 rows straddle task boundaries), against the C++ oracle bit for bit."""
+    from oracle import c_oracle
+    from tclip_amd import engine, synth
+    N = 3
+    kw = dict(iters=3, iter_mm=60, lambd=max(1, int(K / 5)) * 75)
+    x_q, _ = synth.make_query_tasks(N, K, seed=9100 + K)
+    res = engine.run_em_dirichlet(x_q.to(DEV), n_batches=1, hard=False, **kw)
+    torch.cuda.synchronize()
+    ref = c_oracle.run(x_q.numpy(), **kw)
+    assert np.array_equal(res.mm_iters[0].cpu().numpy(), ref["mm_iters"])
+    assert np.array_equal(res.alpha.cpu().numpy(), ref["alpha"]), "alpha differs from the oracle's"
+    assert np.array_equal(res.u.cpu().numpy(), ref["u"]), "responsibilities differ from the oracle's"
+    assert np.array_equal(res.v.cpu().numpy(), ref["v"])
+    assert np.array_equal(res.preds.cpu().numpy(), ref["argmax"][-1].astype(np.int32))
