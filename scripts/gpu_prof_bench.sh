@@ -5,7 +5,7 @@ cd /tmp && export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT
 W=${1:-k1000}
 OUT=$R/gpurun_out/prof_bench_$W
-timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT -- python3 $R/bench.py --workload $W --steps 1 --warmup 1 --no-cpu-baseline --no-secondary 2>&1 | tail -1 > $OUT.bench.json
+timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT -- python3 $R/bench.py --workload $W --steps 1 --warmup 1 --no-cpu-baseline --no-secondary 2>&1 | grep "^{" | tail -1 > $OUT.bench.json
 find $OUT -name "*kernel_stats.csv" | head -1 | xargs -I{} cp {} $OUT.kernel_stats.csv
 f=$(find $OUT -name "*kernel_trace.csv" | head -1)
 head -1 $f > $OUT.kernel_trace_head.csv; grep -m 3 "k_mm_live<.*false" $f >> $OUT.kernel_trace_head.csv; grep -m 3 "k_mm_split<" $f >> $OUT.kernel_trace_head.csv
