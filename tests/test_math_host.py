@@ -130,7 +130,7 @@ def test_lgamma_fp64_form_agrees_on_every_float_of_2p3_to_2e41(mc):
 
 def test_no_shift_lgamma_form_agrees_on_every_float_above_7(mc):
     """class C of the split MM kernel (alpha + 1 >= 10) evaluates Sleef's large-argument lgamma without the argument shift
-    and with a 30-bit logarithm of the Stirling correction (lgamma_sleef_gt7_f64): against the double-float restatement
+    and with the logarithm of the Stirling correction as a six-term log1p series (lgamma_sleef_gt7_f64): against the double-float restatement
     on EVERY float of (7, 2^41]"""
     import struct
     bits = lambda v: struct.unpack("<I", struct.pack("<f", v))[0]

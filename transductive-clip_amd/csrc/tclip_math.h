@@ -500,26 +500,19 @@ TCLIP_HD double logk2f_f64(float hi, double val) {
     const double x2 = x * x;
     return __builtin_fma((double)e, kLn2Df, __builtin_fma(x2 * x, (double)t, x + x));
 }
-// logk2f_f64 for an argument in [1, 1.25): the exponent split is 2^0 (hi * 4/3 lies in [1.33, 1.67)), and - for the one
-// caller, the Stirling correction 1 + u t <= 1.012 of an argument above 7, whose logarithm is at most 1e-3 of the
-// lgamma value it is added to - the quotient needs ~30 good bits, which one Newton step on the fp32 reciprocal gives
-// (the general form polishes the quotient to 2^-52).  The fp32 quantities Sleef's polynomial sees are the same.
-template <bool kFast>
-TCLIP_HD double logk2f_f64_near1(float hi, double val) {
-    const float nx = hi + -1.0f, dnx = hi + 1.0f;
-    const float tq = rcp_ieee<kFast>(dnx);
-    const float xx = nx * tq;
-    const float x2x = xx * xx;
-    float t = 0.2392828464508056640625f;
-    t = __builtin_fmaf(t, x2x, 0.28518211841583251953125f);
-    t = __builtin_fmaf(t, x2x, 0.400005877017974853515625f);
-    t = __builtin_fmaf(t, x2x, 0.666666686534881591796875f);
-    const double N = val - 1.0, D = val + 1.0;
-    double r = (double)tq;
-    r = __builtin_fma(r, __builtin_fma(-D, r, 1.0), r);
-    const double x = N * r;
-    const double x2 = x * x;
-    return __builtin_fma(x2 * x, (double)t, x + x);
+// Logarithm of the Stirling correction 1 + w, w = u t <= 0.012, of an argument above 7 (no shift product: Sleef's
+// logk2f sees corr itself).  At this size Sleef's own approximations vanish (its series 2x + x^3 t(x^2) with x = w / (2 + w)
+// <= 0.006 differs from the logarithm by < 1e-14 absolute, its double-float rounding by less), so the fp32 quantities of
+// that call need no reproduction: log1p(w) by its series to w^6 (remainder w^7 / 7 < 5e-15 against values >= lgamma(7) = 6.6),
+// six fp64 operations instead of a reciprocal, a Newton step and the polynomial.  Checked like every other form: every
+// float of (7, 2^41] against the double-float restatement (mc_lgamma_gt7_f64_form).
+TCLIP_HD double log1p_small_f64(double w) {
+    double p = __builtin_fma(w, -1.0 / 6.0, 1.0 / 5.0);
+    p = __builtin_fma(p, w, -1.0 / 4.0);
+    p = __builtin_fma(p, w, 1.0 / 3.0);
+    p = __builtin_fma(p, w, -1.0 / 2.0);
+    p = __builtin_fma(p, w, 1.0);
+    return p * w;
 }
 TCLIP_HD uint32_t f64_distance_from_f32_midpoint(double v) {
     const uint32_t below = (uint32_t)f64_bits(v) & 0x1fffffffu;
@@ -551,12 +544,12 @@ TCLIP_HD float lgamma_sleef_ge23_f64_core(float a, double& pd, double& v) {
     constexpr double kHalfLog2PiDf = (double)(float)kHalfLog2Pi + (double)(float)(kHalfLog2Pi - (double)(float)kHalfLog2Pi);
     double c = __builtin_fma(xd - 0.5, logk2f_f64<kFast>(xh, xd), -xd) + kHalfLog2PiDf;
     // corr = 1 + u t (u t is exact in fp64), divided by the shift product
-    const float ch = u * t + 1.0f;                                 // hi word of corr
-    const double cd = __builtin_fma((double)u, (double)t, 1.0);
-    if (kGt7) {                                                    // prod = 1: tp = 1, qh = ch * 1, rp = 1, qd = cd exactly
-        v = c + logk2f_f64_near1<kFast>(ch, cd);
+    if (kGt7) {                                                    // prod = 1: the quotient is corr itself
+        v = c + log1p_small_f64((double)u * (double)t);
         return (float)v;
     }
+    const float ch = u * t + 1.0f;                                 // hi word of corr
+    const double cd = __builtin_fma((double)u, (double)t, 1.0);
     const float tp = rcp_ieee<kFast>(ph);
     const float qh = ch * tp;                                      // hi word of corr / prod as df_div forms it
     double rp = (double)tp;
