@@ -1594,10 +1594,9 @@ __global__ __launch_bounds__(256) void k_softmax(const float* logit0, const floa
 // alpha_old <- alpha, with torch's fp32 norm: `x.norm(dim=(1,2))` is ONE serial pass over the task's K*K elements
 // with eight fused multiply-add accumulators by element index mod 8, the accumulators added in order, the n mod 8
 // tail (first four as product + add, the rest fused), one correctly rounded square root (probed bit for bit up to
-// 10^6 elements, oracle/mathcheck.cpp::mc_norm8).  One wavefront per task: 64 consecutive elements per step, lane j < 8
-// owns accumulator j and takes its eight operands of the step from lanes j, 8 + j, ..., 56 + j in order; eight steps of
-// loads are in flight at a time (the chain of n/8 dependent FMAs per accumulator is inherent, the kernel lives on
-// memory latency; a variant with four tasks per wavefront and DPP operands had a quarter of the wavefronts and was slower).
+// 10^6 elements, oracle/mathcheck.cpp::mc_norm8).  One wavefront per task; lane j (and its seven copies 8 i + j) owns
+// accumulator j.  The chain of n/8 dependent FMAs per accumulator is inherent; everything else is kept off it (main loop
+// below).  (A variant with four tasks per wavefront and DPP operands had a quarter of the wavefronts and was slower.)
 __global__ __launch_bounds__(64) void k_criterion(const float* __restrict__ alpha, float* __restrict__ alpha_old, int K, int T,
                                                   float* __restrict__ ratio) {
     const int t = blockIdx.x, lane = threadIdx.x, j = lane & 7;
@@ -1613,25 +1612,50 @@ __global__ __launch_bounds__(64) void k_criterion(const float* __restrict__ alph
         }
     };
     size_t s0 = 0;
-    constexpr int kDepth = 8;
-    for (; s0 + 64 * kDepth <= nv; s0 += 64 * kDepth) {
+    // Main loop, 512 elements at a time: the wavefront loads them coalesced, writes alpha_old, and transposes the pairs (d = o - c, o)
+    // through LDS so that lane j finds the 64 operand pairs of accumulator j (elements j, 8 + j, ..., 504 + j of the block) contiguous
+    // in its row; the rows are read back as 16-byte vectors and feed the two FMA chains (one packed FMA per pair), while the next
+    // block's global loads are in flight.  (Round 2 fetched every operand with a cross-lane shuffle: 16 per 64 elements in front of 16 dependent FMAs,
+    // ~400 cycles per 64 elements where the chains need ~100; one wavefront per task has nothing else to hide that behind,
+    // which the few-shot runs - 33 tasks per stream - paid 20 times per run.)
+    constexpr int kDepth = 8, kRow = 64 + 4;                  // rows of 64 (d, o) pairs, 68 apart: the transposing 8-byte writes of a half-wavefront hit 32 different bank pairs
+    __shared__ __attribute__((aligned(16))) float2 sdo[8 * kRow];
+    if (s0 + 64 * kDepth <= nv) {
+        const int wi = lane >> 3;                             // this lane holds operand 8 k + wi of accumulator j in chunk k
         float o[kDepth], c[kDepth];
 #pragma unroll
         for (int k = 0; k < kDepth; k++) {
             o[k] = alpha_old[base + s0 + 64 * k + lane];
             c[k] = alpha[base + s0 + 64 * k + lane];
         }
+        f2 acc{0.0f, 0.0f};                                   // {acc_d, acc_o}: the two chains share packed FMAs
+        for (bool more = true; more;) {
 #pragma unroll
-        for (int k = 0; k < kDepth; k++) {
-            alpha_old[base + s0 + 64 * k + lane] = c[k];
-#pragma unroll
-            for (int i = 0; i < 8; i++) {
-                const float d = o[k] - c[k];
-                const float vd = __shfl(d, 8 * i + j, 64), vo = __shfl(o[k], 8 * i + j, 64);
-                acc_d = __builtin_fmaf(vd, vd, acc_d);
-                acc_o = __builtin_fmaf(vo, vo, acc_o);
+            for (int k = 0; k < kDepth; k++) {
+                alpha_old[base + s0 + 64 * k + lane] = c[k];
+                sdo[j * kRow + 8 * k + wi] = float2{o[k] - c[k], o[k]};
             }
+            s0 += 64 * kDepth;
+            more = s0 + 64 * kDepth <= nv;
+            if (more) {
+#pragma unroll
+                for (int k = 0; k < kDepth; k++) {
+                    o[k] = alpha_old[base + s0 + 64 * k + lane];
+                    c[k] = alpha[base + s0 + 64 * k + lane];
+                }
+            }
+            __syncthreads();                                  // one wavefront per block: orders the LDS writes before the reads
+#pragma unroll
+            for (int m = 0; m < 32; m++) {
+                const float4 v = *reinterpret_cast<const float4*>(&sdo[j * kRow + 2 * m]);
+                const f2 p0{v.x, v.y}, p1{v.z, v.w};
+                acc = pk_fma(p0, p0, acc);
+                acc = pk_fma(p1, p1, acc);
+            }
+            __syncthreads();                                  // ... and the reads before the next block's writes
         }
+        acc_d = acc.x;
+        acc_o = acc.y;
     }
     for (; s0 + 64 <= nv; s0 += 64) {
         const float o = alpha_old[base + s0 + lane], c = alpha[base + s0 + lane];
