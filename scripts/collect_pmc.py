@@ -6,7 +6,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 tag = sys.argv[1] if len(sys.argv) > 1 else "r02"
 commit = subprocess.run(["git", "rev-parse", "--short", "HEAD"], cwd=ROOT, capture_output=True, text=True).stdout.strip()
 out = {}
-for key in ("k1000", "k100"):
+for key in ("k1000", "k100", "k397_hard", "fs_k1000"):
     p = os.path.join(ROOT, "gpurun_out", f"pmc_{key}.json")
     if not os.path.exists(p):
         continue
