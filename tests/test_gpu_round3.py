@@ -185,3 +185,29 @@ def test_e_step_at_the_edges_of_every_row_width_bucket(K):
     assert np.array_equal(res.u.cpu().numpy(), ref["u"]), "responsibilities differ from the oracle's"
     assert np.array_equal(res.v.cpu().numpy(), ref["v"])
     assert np.array_equal(res.preds.cpu().numpy(), ref["argmax"][-1].astype(np.int32))
+
+
+def test_integration_md_level2_binding_is_live():
+    """The ctypes binding INTEGRATION.md shows a maintainer of the reference (Level 2) is executed AS PRINTED - the code block is
+    cut out of the document, only the library path is filled in - bound to a stand-in for the reference's method object, and run on
+    a reference fixture: alpha, u, v and the criterions it leaves on the object are the reference's, bit for bit.  Nothing of this
+    repository's Python (tclip_amd) is involved: the C ABI alone carries the path."""
+    import re
+    import types
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    text = open(os.path.join(root, "INTEGRATION.md")).read()
+    section = text[text.index("## Level 2"):]
+    code = re.search(r"```python\n(.*?)```", section, re.S).group(1)
+    lib_path = os.path.join(root, "transductive-clip_amd", "tclip_amd", "libtclip.so")
+    assert 'ctypes.CDLL("libtclip.so")' in code
+    ns = {}
+    exec(compile(code.replace('ctypes.CDLL("libtclip.so")', f"ctypes.CDLL({lib_path!r})"), "INTEGRATION.md:level2", "exec"), ns)
+    g = np.load(os.path.join(GOLDEN, "zs_soft_K47_N3.npz"))
+    K = int(g["K"])
+    method = types.SimpleNamespace(iter=int(g["iters"]), iter_mm=int(g["iter_mm"]), lambd=int(K / 5) * 75, device=DEV)
+    query = torch.from_numpy(g["x_q"]).to(DEV)
+    ns["run_method"](method, query, torch.from_numpy(g["y_q"]).to(DEV))
+    assert np.array_equal(method.alpha.cpu().numpy(), g["alpha"])
+    assert np.array_equal(method.u.cpu().numpy(), g["u"])
+    assert np.array_equal(method.v.cpu().numpy(), g["v"])
+    assert np.array_equal(np.array([float(c) for c in method.criterions], np.float32), g["criterions"])
