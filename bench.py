@@ -54,6 +54,7 @@ os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "transductive-clip_amd"))
+sys.path.insert(0, os.path.join(ROOT, "transductive-clip_amd", "drop_in"))
 
 import torch  # noqa: E402
 

@@ -26,8 +26,9 @@ extern "C" {
 #endif
 
 /* 2: tclip_alpha_tim_run, tclip_laplacian_shot_run, tclip_match_clusters_host_strided, tclip_debug_set_mm_split added
- * (every version-1 entry point keeps its signature) */
-#define TCLIP_ABI_VERSION 2
+ * 3: tclip_em_dirichlet_run_tasks (tclip_task_source) added
+ * (every entry point of an earlier version keeps its signature) */
+#define TCLIP_ABI_VERSION 3
 
 enum {
     TCLIP_OK = 0,
@@ -72,6 +73,30 @@ size_t tclip_workspace_bytes(const tclip_problem* p);
 int tclip_em_dirichlet_run(const tclip_problem* p, const float* x_q, const float* x_s, const int64_t* y_s,
                            float* u, float* v, float* alpha, int32_t* preds, float* criterions,
                            int32_t* mm_iters, void* workspace, size_t workspace_bytes, void* stream);
+
+/* The same loop fed from the feature TABLES of the task-batch loop instead of per-task tensors: what
+ *     src/eval_few_shot.py:233-241            all_features_{support,query}[indices, :]   (zero-shot: eval_zero_shot.py:160-163)
+ *     src/task_generator_few_shot.py:41-52    data[:, unique_labels] with unique_labels = flip(unique(labels_support))
+ * materialise as x_s (T,S,K) and x_q (T,Q,K) - 16 MB per task at K = 1000, 4 shots - is read in place: row r of task t is
+ * table[idx[t,r]], its column d is table column cols[t,d].  Results are those of tclip_em_dirichlet_run on the materialised
+ * tensors, bit for bit.
+ *   table_q device [rows_q, K] f32, q_idx device [B*N, Q] i64 (rows of table_q)
+ *   table_s device [rows_s, K] f32, s_idx device [B*N, S] i64 (rows of table_s); both NULL iff S == 0
+ *   cols    device [B*N, K] i32 column permutation per task (applied to both tables), or NULL for the identity
+ *   y_s     device [B*N, S] i64 support labels AFTER get_task's re-indexing (new label j = position of the old label in
+ *           unique_labels), NULL iff S == 0
+ * Index values are not checked on the device: the caller guarantees 0 <= idx < rows and 0 <= cols < K (the Python binding
+ * checks them on the host, where the samplers produce them). */
+typedef struct tclip_task_source {
+    const float* table_q;
+    const int64_t* q_idx;
+    const float* table_s;
+    const int64_t* s_idx;
+    const int32_t* cols;
+} tclip_task_source;
+int tclip_em_dirichlet_run_tasks(const tclip_problem* p, const tclip_task_source* src, const int64_t* y_s,
+                                 float* u, float* v, float* alpha, int32_t* preds, float* criterions,
+                                 int32_t* mm_iters, void* workspace, size_t workspace_bytes, void* stream);
 
 /* Accuracy tail, device half: per task the clusters present in `preds` in first-appearance order
  * and the mean raw feature of each (compute_acc_clustering, em_dirichlet.py:61-71).

@@ -1,5 +1,5 @@
 import sys, os, time, numpy as np, torch
-sys.path.insert(0,'/root/repo'); sys.path.insert(0,'/root/repo/transductive-clip_amd')
+sys.path.insert(0,'/root/repo'); sys.path.insert(0,'/root/repo/transductive-clip_amd'); sys.path.insert(0,'/root/repo/transductive-clip_amd/drop_in')
 from tclip_amd import engine
 dev=torch.device('cuda:0')
 for name in sys.argv[1:]:

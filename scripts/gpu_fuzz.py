@@ -6,7 +6,7 @@ Random (K, Q, tasks, batches, hard, few-shot, schedule) against the C++ oracle, 
 case run twice (run-to-run determinism)."""
 import os, random, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "transductive-clip_amd"))
+sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "transductive-clip_amd")); sys.path.insert(0, os.path.join(ROOT, "transductive-clip_amd", "drop_in"))
 import numpy as np
 import torch
 from oracle import c_oracle

@@ -9,7 +9,7 @@ on platform-independent inputs: exact).  EM_GAUSSIAN_COV multiplies by inverse v
 difference of the host's log can exceed the tolerance: its column is printed but not counted."""
 import os, random, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "transductive-clip_amd"))
+sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "transductive-clip_amd")); sys.path.insert(0, os.path.join(ROOT, "transductive-clip_amd", "drop_in"))
 import torch
 from oracle import ref_torch
 from tclip_amd import engine, synth

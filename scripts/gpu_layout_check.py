@@ -1,7 +1,7 @@
 """default layout against the forced 32-lane layout on one K: python3 scripts/gpu_layout_check.py K [N]"""
 import os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "transductive-clip_amd"))
+sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "transductive-clip_amd")); sys.path.insert(0, os.path.join(ROOT, "transductive-clip_amd", "drop_in"))
 import torch
 from tclip_amd import engine, synth
 K = int(sys.argv[1]); N = int(sys.argv[2]) if len(sys.argv) > 2 else 3

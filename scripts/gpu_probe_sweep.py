@@ -1,7 +1,7 @@
 """K=1000 wall time against the number of probed chunks: python3 scripts/gpu_probe_sweep.py"""
 import os, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "transductive-clip_amd"))
+sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "transductive-clip_amd")); sys.path.insert(0, os.path.join(ROOT, "transductive-clip_amd", "drop_in"))
 import torch
 from tclip_amd import engine, synth
 x, _ = synth.make_query_tasks(250, 1000, seed=5); x = x.cuda()

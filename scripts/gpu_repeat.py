@@ -1,7 +1,7 @@
 """Run-to-run repeatability of the engine: python3 scripts/gpu_repeat.py K n_batches tasks_per_batch [repeats]"""
 import os, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "transductive-clip_amd"))
+sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "transductive-clip_amd")); sys.path.insert(0, os.path.join(ROOT, "transductive-clip_amd", "drop_in"))
 import torch
 from tclip_amd import engine, synth
 K, B, N = int(sys.argv[1]), int(sys.argv[2]), int(sys.argv[3])

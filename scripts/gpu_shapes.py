@@ -1,7 +1,7 @@
 """Wall time of the engine on the other BASELINE shapes (run on the GPU box): python3 scripts/gpu_shapes.py"""
 import os, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "transductive-clip_amd"))
+sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "transductive-clip_amd")); sys.path.insert(0, os.path.join(ROOT, "transductive-clip_amd", "drop_in"))
 import torch
 from tclip_amd import engine, synth
 

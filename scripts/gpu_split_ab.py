@@ -3,7 +3,7 @@
 python scripts/gpu_split_ab.py [K B N iters]...  prints total seconds per mode and checks the results are identical."""
 import os, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "transductive-clip_amd"))
+sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "transductive-clip_amd")); sys.path.insert(0, os.path.join(ROOT, "transductive-clip_amd", "drop_in"))
 import torch
 from tclip_amd import _capi, engine, synth
 

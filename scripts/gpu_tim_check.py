@@ -9,7 +9,7 @@ import numpy as np
 import torch
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-sys.path.insert(0, os.path.join(ROOT, "transductive-clip_amd"))
+sys.path.insert(0, os.path.join(ROOT, "transductive-clip_amd")); sys.path.insert(0, os.path.join(ROOT, "transductive-clip_amd", "drop_in"))
 from tclip_amd import engine, synth  # noqa: E402
 
 for path in sorted(glob.glob(os.path.join(ROOT, "tests", "golden", "fs_tim_*.npz"))):

@@ -1,7 +1,7 @@
 """SOFT_KMEANS workload for kernel-time breakdown: python3 scripts/prof_kmeans.py [K] [tasks] [iters]"""
 import os, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "transductive-clip_amd"))
+sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "transductive-clip_amd")); sys.path.insert(0, os.path.join(ROOT, "transductive-clip_amd", "drop_in"))
 import torch
 from tclip_amd import engine, synth
 K = int(sys.argv[1]) if len(sys.argv) > 1 else 397

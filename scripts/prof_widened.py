@@ -1,7 +1,7 @@
 """The widened methods once each, for a kernel-time breakdown: python3 scripts/prof_widened.py"""
 import os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "transductive-clip_amd"))
+sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "transductive-clip_amd")); sys.path.insert(0, os.path.join(ROOT, "transductive-clip_amd", "drop_in"))
 import torch
 from tclip_amd import engine, synth
 T, K = 1000, 397

@@ -5,8 +5,9 @@ import pytest
 import torch
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-PKG = os.path.join(ROOT, "transductive-clip_amd")
-for p in (ROOT, PKG):
+PKG = os.path.join(ROOT, "transductive-clip_amd")        # holds tclip_amd (the engine) - the only entry INTEGRATION.md puts on PYTHONPATH
+DROP_IN = os.path.join(PKG, "drop_in")                   # holds src/ (reference-named classes): NOT on the path of a Level-1 user
+for p in (ROOT, PKG, DROP_IN):
     if p not in sys.path:
         sys.path.insert(0, p)
 GOLDEN = os.path.join(ROOT, "tests", "golden")

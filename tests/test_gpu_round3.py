@@ -142,23 +142,45 @@ def test_class_split_kernel_is_invisible(K, N, few, hard):
     assert torch.isfinite(res[0].alpha).all()
 
 
-def test_class_split_kernel_with_nan_and_stopped_batches():
-    """A NaN feature (the block-uniform generic path inside k_mm_split) and a batch that stops early while the other keeps
-    iterating (rows of a stopped batch are skipped by the same blocks): identical to k_mm_live."""
+def _mm_launch_names(fn):
+    """kernel names of the launches `fn` makes, from torch's profiler (roctracer): which MM kernel a test really ran"""
+    from torch.profiler import ProfilerActivity, profile
+    with profile(activities=[ProfilerActivity.CUDA]) as prof:
+        fn()
+        torch.cuda.synchronize()
+    return {e.name for e in prof.events() if "k_mm_" in e.name}
+
+
+@pytest.mark.parametrize("K,N,iter_mm", [(100, 4, 1000), (397, 2, 400), (1000, 2, 400)])
+def test_class_split_kernel_with_nan_and_stopped_batches(K, N, iter_mm):
+    """A NaN feature (the per-wavefront generic path inside k_mm_split: mm_iterate_wave_split's `!__all(in_domain)` branch)
+    and a batch that stops early while the other keeps iterating (rows of a stopped batch are skipped by the same
+    blocks): identical to k_mm_live.  Row lengths WITH a split instantiation in each lane layout: K = 100 (16 lanes x 7
+    registers), 397 (32 x 13), 1000 (64 x 16) - round 3 ran this at K = 40, three registers per lane, below
+    TCLIP_SPLIT_MIN_E, where both modes are k_mm_live and the test passed trivially.  The profiler's kernel names
+    confirm that mode 1 launched k_mm_split and mode 0 did not."""
     from tclip_amd import engine, synth
-    K, N, B = 40, 4, 2
-    x_q, _ = synth.make_query_tasks(B * N, K, seed=8300)
+    B = 2
+    x_q, _ = synth.make_query_tasks(B * N, K, seed=8300 + K)
+    # batch 1: nearly flat features - its MM loop stops at an early checkpoint while batch 0 runs on
+    x_q[N:] = torch.softmax(torch.log(x_q[N:]) * 0.02, -1)
     x_bad = x_q.clone()
     x_bad[1, 3, 5] = float("nan")
-    kw = dict(n_batches=B, iters=4, iter_mm=1000, lambd=int(K / 5) * 75, hard=False)
-    out = {}
+    kw = dict(n_batches=B, iters=3, iter_mm=iter_mm, lambd=int(K / 5) * 75, hard=False)
+    out, names = {}, {}
     try:
         for mode in (0, 1):
             _set_split(mode)
-            out[mode] = (engine.run_em_dirichlet(x_q.to(DEV), **kw), engine.run_em_dirichlet(x_bad.to(DEV), **kw))
-            torch.cuda.synchronize()
+            def go():
+                out[mode] = (engine.run_em_dirichlet(x_q.to(DEV), **kw), engine.run_em_dirichlet(x_bad.to(DEV), **kw))
+            names[mode] = _mm_launch_names(go)
     finally:
         _set_split(-1)
+    assert any("k_mm_split" in n for n in names[1]), names[1]
+    assert not any("k_mm_split" in n for n in names[0]), names[0]
+    clean = out[0][0].mm_iters.cpu().numpy()
+    assert (clean[1] < iter_mm).any() and (clean[0] > clean[1]).any(), f"batch 1 should stop before batch 0: {clean.tolist()}"
+    assert torch.isnan(out[0][1].alpha[1]).any(), "the NaN feature must reach alpha (the generic path ran)"
     for a, b in zip(out[0], out[1]):
         for name in ("alpha", "u", "v", "preds", "mm_iters"):
             x, y = getattr(a, name), getattr(b, name)

@@ -165,3 +165,25 @@ def test_more_ranks_than_batches_gloo(tmp_path):
     out = str(tmp_path / "gathered.pt")
     mp.spawn(_worker_idle_rank, args=(2, 29500 + ((os.getpid() + 991) % 2000), out), nprocs=2, join=True)
     assert torch.equal(torch.load(out), torch.full((1, 4), 7.0))
+
+
+def test_relabel_indices_equals_get_task_relabelling():
+    """Evaluator_few_shot's index-only relabelling (column permutation + re-indexed labels, no feature tensor touched) against
+    relabel(), the restatement of Tasks_Generator_few_shot.get_task (task_generator_few_shot.py:41-52), task by task; a support
+    set that misses a class is reported as None (the evaluator then materialises the task tensors)."""
+    from src.eval_few_shot import relabel_indices
+    from src.task_generator_few_shot import relabel
+    gen = torch.Generator().manual_seed(5)
+    K, T, S, Q = 7, 5, 14, 9
+    y_s = torch.stack([torch.arange(K).repeat_interleave(2)[torch.randperm(S, generator=gen)] for _ in range(T)])
+    y_q = torch.randint(0, K, (T, Q), generator=gen)
+    x_s, x_q = torch.rand(T, S, K, generator=gen), torch.rand(T, Q, K, generator=gen)
+    cols, ys2, yq2 = relabel_indices(y_s, y_q, K)
+    assert cols.dtype == torch.int32 and tuple(cols.shape) == (T, K)
+    for t in range(T):
+        xs_ref, xq_ref, ys_ref, yq_ref = relabel(x_s[t], x_q[t], y_s[t], y_q[t], True)
+        assert torch.equal(x_s[t][:, cols[t].long()], xs_ref) and torch.equal(x_q[t][:, cols[t].long()], xq_ref)
+        assert torch.equal(ys2[t], ys_ref) and torch.equal(yq2[t], yq_ref)
+    y_missing = y_s.clone()
+    y_missing[2][y_missing[2] == 3] = 4
+    assert relabel_indices(y_missing, y_q, K) is None

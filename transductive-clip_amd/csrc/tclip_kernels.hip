@@ -76,6 +76,35 @@ __global__ void k_copy(const float* __restrict__ s, float* __restrict__ d, size_
 
 __global__ void k_one_row_list(int32_t* __restrict__ rows, int32_t* __restrict__ n) { rows[0] = 0; n[0] = 1; }
 
+// Where the feature rows of a call come from: a dense (T, R, K) tensor (idx == nullptr), or rows of a feature TABLE named by
+// an index tensor, optionally with a per-task column permutation - the task-batch loop's `all_features[indices, :]`
+// (eval_few_shot.py:233-241) and Tasks_Generator_few_shot.get_task's `data[:, unique_labels]`
+// (task_generator_few_shot.py:41-52) read in place instead of materialised.
+struct RowSrc {
+    const float* base;       // dense: row r at base + r K;  indexed: the table
+    const int64_t* idx;      // [T * R] table rows, or nullptr
+    const int32_t* cols;     // [T, K]: column d of task t is table column cols[t K + d], or nullptr (identity)
+};
+static RowSrc dense_rows(const float* x) { return RowSrc{x, nullptr, nullptr}; }
+
+// u = z and log z = log(z + 1e-15) of an indexed source, one pass over the table rows (em_dirichlet.py:38, :206)
+__global__ __launch_bounds__(256) void k_gather_log_features(RowSrc src, int rows_per_task, int K, size_t n_rows, float* __restrict__ u,
+                                                             float* __restrict__ logz, int32_t* __restrict__ nonfinite) {
+    bool bad = false;
+    for (size_t r = blockIdx.x; r < n_rows; r += gridDim.x) {
+        const float* row = src.base + (size_t)src.idx[r] * K;
+        const int32_t* c = src.cols ? src.cols + (r / rows_per_task) * K : nullptr;
+        for (int d = threadIdx.x; d < K; d += blockDim.x) {
+            const float x = row[c ? c[d] : d];
+            const float v = log_f32(x + kEpsF);
+            u[r * K + d] = x;
+            logz[r * K + d] = v;
+            bad = bad || (f32_bits(v) & 0x7f800000u) == 0x7f800000u;
+        }
+    }
+    if (nonfinite && bad) atomicOr(nonfinite, 1);
+}
+
 // p[i] = p[0] for 0 < i < n
 __global__ void k_broadcast_first(float* p, size_t n) {
     const float v = p[0];
@@ -131,7 +160,7 @@ struct SparseCascade {
 // it).  Because a1 then holds exactly what the first dump put there, replaying "first level-1
 // boundary, then first level-2 boundary >= it, then first level-3 boundary >= that" is equivalent.
 
-__global__ void k_support_stats(const float* __restrict__ xs, const int64_t* __restrict__ ys, int S, int K, int take_log,
+__global__ void k_support_stats(RowSrc src, const int64_t* __restrict__ ys, int S, int K, int take_log,
                                 float* __restrict__ sup, float* __restrict__ cnt) {
     extern __shared__ int members[];               // indices s with ys == k, ascending
     __shared__ int n_members;
@@ -159,7 +188,10 @@ __global__ void k_support_stats(const float* __restrict__ xs, const int64_t* __r
         __syncthreads();
     }
     const int nm = n_members;
-    const float* xt = xs + (size_t)t * S * K;
+    const float* xt = src.base + (src.idx ? 0 : (size_t)t * S * K);
+    const int64_t* it = src.idx ? src.idx + (size_t)t * S : nullptr;
+    const int32_t* ct = src.cols ? src.cols + (size_t)t * K : nullptr;
+    auto fetch = [&](int s_, int d_) { return xt[(size_t)(it ? it[s_] : (int64_t)s_) * K + (ct ? ct[d_] : d_)]; };
     const long ncols = (long)K * K;
     for (int d = threadIdx.x; d < K; d += blockDim.x) {
         const long col = (long)k * K + d;
@@ -167,7 +199,7 @@ __global__ void k_support_stats(const float* __restrict__ xs, const int64_t* __r
         if (outer_column_is_cascade(col, ncols)) {
             SparseCascade c(S);
             for (int i = 0; i < nm; i++) {
-                const float x = xt[(size_t)members[i] * K + d];
+                const float x = fetch(members[i], d);
                 c.add(members[i], take_log ? log_f32(x + kEpsF) : x);
             }
             r = c.finish();
@@ -180,7 +212,7 @@ __global__ void k_support_stats(const float* __restrict__ xs, const int64_t* __r
             // leftovers are added after partial 0's cascade is complete, in order
             for (int i = 0; i < nm; i++) {
                 const int s = members[i];
-                const float x = xt[(size_t)s * K + d];
+                const float x = fetch(s, d);
                 const float v = take_log ? log_f32(x + kEpsF) : x;
                 if (s >= size_ilp * 4) {
                     if (!has_extra) { p0 = c0.finish(); has_extra = true; }
@@ -993,6 +1025,16 @@ __device__ __forceinline__ void split_apply_updates(float (&beta)[E], const RowY
     }
 }
 
+// Lanes of one wavefront hand data to each other through the wavefront's LDS planes at three places of an iteration
+// (phase A's scatter -> the dense passes -> phase C's pick-up -> the next iteration's scatter).  The hardware executes a
+// wavefront's LDS operations in order; this keeps the COMPILER from moving a may-alias access across a hand-off
+// (wavefront-scope fences generate no instructions).
+__device__ __forceinline__ void wave_lds_handoff() {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
 // my0 / my1: the wavefront's two planes of 64 E words
 template <int E, int G>
 __device__ __forceinline__ void mm_iterate_wave_split(float (&beta)[E], const RowY<E, G, TCLIP_SPLIT_Y_REGS_MAX_E>& yv, int K, int lane, bool active,
@@ -1084,6 +1126,7 @@ __device__ __forceinline__ void mm_iterate_wave_split(float (&beta)[E], const Ro
         cC += __popcll(mC);
     }
     const float psi_s = digamma_pos_f32(s, tab);                    // the row sums of the wavefront's rows, one evaluation
+    wave_lds_handoff();
     // phase B: the queues in dense passes; entry i leaves with lgamma(a+1) in plane 0 and digamma(a+1) in plane 1
     int jA = 0;
     for (; jA + 64 < nA; jA += 128) {                               // more than 64 entries left: two per lane on the packed pipe
@@ -1159,7 +1202,9 @@ __device__ __forceinline__ void mm_iterate_wave_split(float (&beta)[E], const Ro
         if (ok) { my0[i] = lg; my1[i] = psi; }
     }
     // phase C
+    wave_lds_handoff();
     split_apply_updates<E, G>(beta, yv, K, lane, psi_s, my0, my1, slot, measure, num, den);
+    wave_lds_handoff();
 }
 
 template <int E, int G>
@@ -2287,7 +2332,7 @@ static void launch_mm_EG(int dead, int rows, hipStream_t st, const MMArgs& a) {
     constexpr int kWaves = TCLIP_MM_LAUNCH_WAVES, kRowsPerBlock = (64 / G) * kWaves;
     int grid = (rows + kRowsPerBlock - 1) / kRowsPerBlock;
     if (grid > 256 * 16) grid = 256 * 16;
-    if (dead == kMMSplit) {                        // live rows through the class-split kernel where it exists (E <= 16)
+    if (dead == kMMSplit) {                        // live rows through the class-split kernel where it exists (TCLIP_SPLIT_MIN_E <= E <= TCLIP_SPLIT_MAX_E)
         if constexpr (E <= TCLIP_SPLIT_MAX_E && E >= TCLIP_SPLIT_MIN_E) {
             constexpr int kSplitRows = 64 / G;           // one wavefront per block
             int sgrid = (rows + kSplitRows - 1) / kSplitRows;
@@ -2417,7 +2462,7 @@ namespace tclip {
 
 // Enqueues the whole loop for `p.n_batches` consecutive batches on stream `st`.  `crit_stride` is
 // the row stride (= iters of the full problem) of criterions / mm_iters.
-static int enqueue_batches(const tclip_problem& p, const float* x_q, const float* x_s, const int64_t* y_s, float* u,
+static int enqueue_batches(const tclip_problem& p, const RowSrc& q_src, const RowSrc& s_src, const int64_t* y_s, float* u,
                            float* v, float* alpha, int32_t* preds, float* criterions, int32_t* mm_iters,
                            char* ws, hipStream_t st) {
     const bool zs = p.n_support == 0;
@@ -2452,14 +2497,19 @@ static int enqueue_batches(const tclip_problem& p, const float* x_q, const float
 
     // ---- initialisation (em_dirichlet.py:195-211)
     TCLIP_HIP(hipMemsetAsync(flags, 0, 256, st));
-    hipLaunchKernelGGL(k_log_features, dim3(ew_grid(TQK)), dim3(256), 0, st, x_q, logz, TQK, flags);
-    hipLaunchKernelGGL(k_copy, dim3(ew_grid(TQK)), dim3(256), 0, st, x_q, u, TQK);
+    if (q_src.idx) {            // rows of a feature table through the task-batch loop's index tensor: gather, copy and log in one pass
+        const size_t rows = (size_t)T * Q;
+        hipLaunchKernelGGL(k_gather_log_features, dim3((unsigned)(rows > 65536 ? 65536 : rows)), dim3(256), 0, st, q_src, Q, K, rows, u, logz, flags);
+    } else {
+        hipLaunchKernelGGL(k_log_features, dim3(ew_grid(TQK)), dim3(256), 0, st, q_src.base, logz, TQK, flags);
+        hipLaunchKernelGGL(k_copy, dim3(ew_grid(TQK)), dim3(256), 0, st, q_src.base, u, TQK);
+    }
     hipLaunchKernelGGL(k_fill, dim3(ew_grid(TKK)), dim3(256), 0, st, alpha, 1.0f, TKK);
     hipLaunchKernelGGL(k_fill, dim3(ew_grid(TKK)), dim3(256), 0, st, alpha_old, 1.0f, TKK);
     hipLaunchKernelGGL(k_fill, dim3(ew_grid(TK)), dim3(256), 0, st, v, 0.0f, (size_t)TK);
     TCLIP_HIP(hipMemsetAsync(cache_len, 0, (size_t)TK * 4, st));
     if (!zs) {
-        hipLaunchKernelGGL(k_support_stats, dim3(K, T), dim3(128), (size_t)S * sizeof(int), st, x_s, y_s, S, K, 1, sup, cnt);
+        hipLaunchKernelGGL(k_support_stats, dim3(K, T), dim3(128), (size_t)S * sizeof(int), st, s_src, y_s, S, K, 1, sup, cnt);
     }
     // E-step terms of the initial alpha = 1 for every row (rows that never come alive keep them).  Every
     // row is the same all-ones vector, so lgamma(sum) - sum lgamma is evaluated for ONE row and copied
@@ -2630,17 +2680,16 @@ size_t tclip_workspace_bytes(const tclip_problem* p) {
     return total;
 }
 
-int tclip_em_dirichlet_run(const tclip_problem* pp, const float* x_q, const float* x_s, const int64_t* y_s, float* u,
-                           float* v, float* alpha, int32_t* preds, float* criterions, int32_t* mm_iters,
-                           void* workspace, size_t workspace_bytes, void* stream) {
-    if (int rc = check_problem(pp)) return rc;
-    const tclip_problem p = *pp;
+}  // extern "C"
+
+namespace tclip {
+
+// Splits the call's batches into stream groups and enqueues each group (see StreamPool).
+static int run_em_dirichlet(const tclip_problem& p, const RowSrc& q_src, const RowSrc& s_src, const int64_t* y_s, float* u,
+                            float* v, float* alpha, int32_t* preds, float* criterions, int32_t* mm_iters,
+                            void* workspace, size_t workspace_bytes, void* stream) {
     const bool zs = p.n_support == 0;
-    if (!x_q || !u || !v || !alpha || !preds || !criterions || !mm_iters || !workspace)
-        return fail(TCLIP_ERR_ARG, "null pointer argument");
-    if (zs != (x_s == nullptr) || zs != (y_s == nullptr))
-        return fail(TCLIP_ERR_ARG, "x_s and y_s must be given exactly when n_support > 0");
-    if (workspace_bytes < tclip_workspace_bytes(pp)) return fail(TCLIP_ERR_WORKSPACE, "workspace smaller than tclip_workspace_bytes()");
+    if (workspace_bytes < tclip_workspace_bytes(&p)) return fail(TCLIP_ERR_WORKSPACE, "workspace smaller than tclip_workspace_bytes()");
     if (((uintptr_t)workspace & 255) != 0) return fail(TCLIP_ERR_WORKSPACE, "workspace must be 256-byte aligned");
     hipStream_t caller = (hipStream_t)stream;
     const int G = n_groups_of(p);
@@ -2654,6 +2703,12 @@ int tclip_em_dirichlet_run(const tclip_problem* pp, const float* x_q, const floa
         int b0;
         ws_off[g + 1] = ws_off[g] + make_layout(group_problem(p, g, &b0)).total;
     }
+    // the rows of the tasks from t0 on: a dense tensor moves its base, an indexed source its index (and column) rows
+    auto from_task = [&](const RowSrc& src, size_t t0, size_t rows_per_task) {
+        if (!src.base) return src;
+        if (src.idx) return RowSrc{src.base, src.idx + t0 * rows_per_task, src.cols ? src.cols + t0 * K : nullptr};
+        return RowSrc{src.base + t0 * rows_per_task * K, nullptr, nullptr};
+    };
     for (int i = 0; i < G; i++) {
         const int g = (i + 1) % G;                       // pool streams first, the caller's stream last
         int b0;
@@ -2663,7 +2718,7 @@ int tclip_em_dirichlet_run(const tclip_problem* pp, const float* x_q, const floa
         if (g != 0) TCLIP_HIP(hipStreamWaitEvent(st, g_pool.fork, 0));
         tclip_problem qs = q;
         qs.iters = p.iters;
-        if (int rc = enqueue_batches(qs, x_q + t0 * Q * K, zs ? nullptr : x_s + t0 * S * K, zs ? nullptr : y_s + t0 * S,
+        if (int rc = enqueue_batches(qs, from_task(q_src, t0, Q), from_task(s_src, t0, S), zs ? nullptr : y_s + t0 * S,
                                      u + t0 * Q * K, v + t0 * K, alpha + t0 * K * K, preds + t0 * Q,
                                      criterions + (size_t)b0 * p.iters, mm_iters + (size_t)b0 * p.iters,
                                      (char*)workspace + ws_off[g], st)) {
@@ -2676,6 +2731,36 @@ int tclip_em_dirichlet_run(const tclip_problem* pp, const float* x_q, const floa
     }
     for (int g = 1; g < G; g++) TCLIP_HIP(hipStreamWaitEvent(caller, g_pool.join[g], 0));
     return TCLIP_OK;
+}
+
+}  // namespace tclip
+
+extern "C" {
+
+int tclip_em_dirichlet_run(const tclip_problem* pp, const float* x_q, const float* x_s, const int64_t* y_s, float* u,
+                           float* v, float* alpha, int32_t* preds, float* criterions, int32_t* mm_iters,
+                           void* workspace, size_t workspace_bytes, void* stream) {
+    if (int rc = check_problem(pp)) return rc;
+    const bool zs = pp->n_support == 0;
+    if (!x_q || !u || !v || !alpha || !preds || !criterions || !mm_iters || !workspace)
+        return fail(TCLIP_ERR_ARG, "null pointer argument");
+    if (zs != (x_s == nullptr) || zs != (y_s == nullptr))
+        return fail(TCLIP_ERR_ARG, "x_s and y_s must be given exactly when n_support > 0");
+    return run_em_dirichlet(*pp, dense_rows(x_q), dense_rows(x_s), y_s, u, v, alpha, preds, criterions, mm_iters, workspace,
+                            workspace_bytes, stream);
+}
+
+int tclip_em_dirichlet_run_tasks(const tclip_problem* pp, const tclip_task_source* src, const int64_t* y_s, float* u,
+                                 float* v, float* alpha, int32_t* preds, float* criterions, int32_t* mm_iters,
+                                 void* workspace, size_t workspace_bytes, void* stream) {
+    if (int rc = check_problem(pp)) return rc;
+    const bool zs = pp->n_support == 0;
+    if (!src || !src->table_q || !src->q_idx || !u || !v || !alpha || !preds || !criterions || !mm_iters || !workspace)
+        return fail(TCLIP_ERR_ARG, "null pointer argument");
+    if (zs != (src->table_s == nullptr) || zs != (src->s_idx == nullptr) || zs != (y_s == nullptr))
+        return fail(TCLIP_ERR_ARG, "table_s, s_idx and y_s must be given exactly when n_support > 0");
+    return run_em_dirichlet(*pp, RowSrc{src->table_q, src->q_idx, src->cols}, RowSrc{src->table_s, src->s_idx, src->cols}, y_s,
+                            u, v, alpha, preds, criterions, mm_iters, workspace, workspace_bytes, stream);
 }
 
 // ---- SOFT_KMEANS (BASELINE config 3's second method)
@@ -2891,7 +2976,7 @@ int tclip_paddle_run(const tclip_problem* pp, const float* x_q, const float* x_s
     float* logit0 = (float*)(ws + o_logit);
     // init (paddle.py:180-197): v = 0, prototypes = class means of the support set; every centroid moves every iteration
     hipLaunchKernelGGL(k_fill, dim3(ew_grid(TK)), dim3(256), 0, st, v, 0.0f, (size_t)TK);
-    hipLaunchKernelGGL(k_support_stats, dim3(K, T), dim3(128), (size_t)S * sizeof(int), st, x_s, y_s, S, K, 0, sup, cnt);
+    hipLaunchKernelGGL(k_support_stats, dim3(K, T), dim3(128), (size_t)S * sizeof(int), st, dense_rows(x_s), y_s, S, K, 0, sup, cnt);
     hipLaunchKernelGGL(k_div_rows, dim3(ew_grid((size_t)TK * K)), dim3(256), 0, st, (const float*)sup, (const float*)cnt,
                        (size_t)TK * K, K, w);
     TCLIP_HIP(hipMemsetAsync(live, 1, (size_t)TK, st));
@@ -2974,7 +3059,7 @@ int tclip_bdcspn_run(const tclip_problem* pp, const float* x_q, const float* x_s
     normalize(x_s, x_s, S, S, norm_type, (const float*)mean, (const float*)nullptr, zs);
     normalize(x_q, x_q, Q, Q, norm_type, (const float*)mean, (const float*)nullptr, zq);
     // initial prototypes: support class means (:117-120), L2-normalised for get_logits (:50)
-    hipLaunchKernelGGL(k_support_stats, dim3(K, T), dim3(128), (size_t)S * sizeof(int), st, (const float*)zs, y_s, S, K, 0, sup, cnt);
+    hipLaunchKernelGGL(k_support_stats, dim3(K, T), dim3(128), (size_t)S * sizeof(int), st, dense_rows(zs), y_s, S, K, 0, sup, cnt);
     hipLaunchKernelGGL(k_div_rows, dim3(ew_grid((size_t)TK * K)), dim3(256), 0, st, (const float*)sup, (const float*)cnt,
                        (size_t)TK * K, K, prototypes);
     normalize((const float*)prototypes, (const float*)prototypes, K, K, 1, (const float*)nullptr, (const float*)nullptr, wn);

@@ -14,7 +14,7 @@ from src.methods.few_shot.bdcspn import BDCSPN
 from src.methods.few_shot.tim import ALPHA_TIM
 from src.methods.few_shot.laplacian_shot import LAPLACIAN_SHOT
 from src.sampler_few_shot import CategoriesSampler_few_shot, SamplerQuery_few_shot, SamplerSupport_few_shot
-from src.task_generator_few_shot import relabel
+from src.task_generator_few_shot import label_permutation, relabel
 from src.utils import Logger, compute_confidence_interval
 from tclip_amd import engine, features, reporting, sharding
 
@@ -31,6 +31,22 @@ def relabel_batch(x_s, x_q, y_s, y_q, use_softmax_feature):
         ys2.append(c_)
         yq2.append(d_)
     return torch.stack(xs2, 0), torch.stack(xq2, 0), torch.stack(ys2, 0), torch.stack(yq2, 0)
+
+
+def relabel_indices(y_s, y_q, n_class):
+    """Tasks_Generator_few_shot.get_task (task_generator_few_shot.py:41-52) for a whole set of tasks WITHOUT touching the
+    features: per task the column permutation `unique_labels` as an int32 row and the re-indexed support / query labels.
+    None when some task's support set misses a class (the permuted task would have fewer than n_class columns; the caller
+    materialises the tensors then, as the reference does)."""
+    cols, ys2, yq2 = [], [], []
+    for t in range(y_s.shape[0]):
+        uniq, lut = label_permutation(y_s[t])
+        if len(uniq) != n_class:
+            return None
+        cols.append(uniq.to(torch.int32))
+        ys2.append(lut[y_s[t].long()])
+        yq2.append(lut[y_q[t].long()])
+    return torch.stack(cols, 0), torch.stack(ys2, 0), torch.stack(yq2, 0)
 
 
 _METHODS = {'EM_DIRICHLET': EM_DIRICHLET, 'HARD_EM_DIRICHLET': HARD_EM_DIRICHLET, 'PADDLE': PADDLE, 'BDCSPN': BDCSPN,
@@ -157,10 +173,24 @@ class Evaluator_few_shot:
         method = self.get_method_builder(model=model, device=self.device, args=a, log_file=self.log_file)
         timestamps, parts = [], None
         runs = [(first_method, mine[:1]), (method, mine[1:])] if first_method is not None else [(method, mine)]
+        ran = None                        # the last method object that actually executed on this rank
         for m, ids in runs:
             if not ids:
                 continue
+            ran = m
             si, qi = s_idx[ids].reshape(-1), q_idx[ids].reshape(-1)
+            # The EM-Dirichlet classes read the task rows from the tables through the index tensors (label flip and column
+            # permutation inside the kernels): x_s (T,S,K) - 1.6 GB per 100 tasks at K = 1000, 4 shots - is never built
+            if hasattr(m, "run_tables") and a.use_softmax_feature and not getattr(a, 'materialise_tasks', False):
+                rel = relabel_indices(lab_s[si].view(-1, S), lab_q[qi].view(-1, Q), K)
+                if rel is not None:
+                    cols, y_s, y_q = rel
+                    m.run_tables(table_s=tab_s, s_idx=si.view(-1, S), table_q=tab_q, q_idx=qi.view(-1, Q), cols=cols,
+                                 y_s=y_s.to(dev), y_q=y_q.to(dev), n_batches=len(ids))
+                    logs = m.get_logs()
+                    parts = sharding.concat_parts(parts, sharding.method_parts(a, m, logs, len(ids), N, Q, dev))
+                    timestamps += [float(logs['timestamps'])] * len(ids)
+                    continue
             x_s = engine.gather_rows(tab_s, si).view(len(ids) * N, S, K)
             x_q = engine.gather_rows(tab_q, qi).view(len(ids) * N, Q, K)
             y_s, y_q = lab_s[si].view(-1, S), lab_q[qi].view(-1, Q)
@@ -175,7 +205,9 @@ class Evaluator_few_shot:
         if parts is None:      # more ranks than batches: this rank only takes part in the gather
             parts = sharding.method_parts(a, None, None, 0, N, Q, dev)
         got = sharding.gather_packed(parts, n_batches)
-        self.last_method = method
+        # a rank whose only batch is batch 0 of a tuned run executes `first_method` alone: `method` never ran there and
+        # carries no records (mm_iters None); a rank without a batch keeps the freshly built object
+        self.last_method = ran if ran is not None else method
         if got is None:
             return None, None
         acc = got['acc'].numpy()

@@ -68,18 +68,24 @@ class EMDirichletBase(object):
         self.test_acc.append(acc.view(-1, 1))
 
     # -- the loop ---------------------------------------------------------------------------
-    def _run_engine(self, query, support=None, y_s=None, n_batches=1):
+    def _run_engine(self, query, support=None, y_s=None, n_batches=1, tables=None):
+        """`tables` = dict(table_q, q_idx[, table_s, s_idx, cols]): the task rows are read from the feature tables through the
+        task-batch loop's index tensors (engine.run_em_dirichlet_tasks) and `query` / `support` are not used"""
         if not self.args.use_softmax_feature:
             raise ValueError(_SIMPLEX_ERROR)
         dev = torch.device(self.device)
         if dev.type != "cuda":
             raise RuntimeError("EM-Dirichlet on MI355X needs device='cuda': there is no CPU fallback in this package")
         self.logger.info(" ==> Executing {} with LAMBDA = {} and T = {}".format(self.BANNER, self.lambd, self.args.T))
-        n_task = query.shape[0]
+        n_task = tables["q_idx"].shape[0] if tables is not None else query.shape[0]
         torch.cuda.synchronize(dev)
         t0 = time.time()
-        res = engine.run_em_dirichlet(query, support, y_s, n_batches=n_batches, iters=self.iter,
-                                      iter_mm=self.iter_mm, lambd=self.lambd, hard=self.HARD)
+        kw = dict(n_batches=n_batches, iters=self.iter, iter_mm=self.iter_mm, lambd=self.lambd, hard=self.HARD)
+        if tables is not None:
+            res = engine.run_em_dirichlet_tasks(tables["table_q"], tables["q_idx"], tables.get("table_s"), tables.get("s_idx"),
+                                                y_s, tables.get("cols"), **kw)
+        else:
+            res = engine.run_em_dirichlet(query, support, y_s, **kw)
         torch.cuda.synchronize(dev)
         total = time.time() - t0
         self.u, self.v, self.alpha, self.preds = res.u, res.v, res.alpha, res.preds
@@ -126,4 +132,13 @@ class FewShotMixin:
         # unlike the reference (few_shot/em_dirichlet.py:186-190) the inputs are left untouched:
         # the engine keeps its own log-features
         self._run_engine(query, support, y_s, n_batches=n_batches)
+        self.compute_acc(y_q=y_q)
+
+    def run_tables(self, table_s, s_idx, table_q, q_idx, cols, y_s, y_q, n_batches=1):
+        """run_method for the task-batch loop (Evaluator_few_shot.evaluate_tasks): the support / query rows of task t are
+        table_s[s_idx[t]] / table_q[q_idx[t]] with the columns permuted by cols[t] (Tasks_Generator_few_shot.get_task's
+        `data[:, unique_labels]`), y_s / y_q the re-indexed labels.  The (T,S,K) support tensor - 16 MB per task at
+        K = 1000 with 4 shots - is never built."""
+        self._run_engine(None, None, y_s, n_batches=n_batches,
+                         tables=dict(table_q=table_q, q_idx=q_idx, table_s=table_s, s_idx=s_idx, cols=cols))
         self.compute_acc(y_q=y_q)

@@ -34,8 +34,9 @@ import torch
 os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")    # see tclip_amd/__init__.py: the engine's streams need their own hardware queues
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-if HERE not in sys.path:
-    sys.path.insert(0, HERE)
+for _p in (HERE, os.path.join(HERE, "drop_in")):          # tclip_amd/ and the reference-named src/ package
+    if _p not in sys.path:
+        sys.path.insert(0, _p)
 
 from src.utils import CfgNode, Logger, load_merged_config, merge_cfg_from_list  # noqa: E402
 from tclip_amd import features, reporting  # noqa: E402

@@ -13,6 +13,10 @@ class Problem(ctypes.Structure):
         "n_batches", "tasks_per_batch", "n_query", "n_class", "n_support", "iters", "iter_mm", "lambd", "hard")]
 
 
+class TaskSource(ctypes.Structure):                 # struct tclip_task_source
+    _fields_ = [(n, ctypes.c_void_p) for n in ("table_q", "q_idx", "table_s", "s_idx", "cols")]
+
+
 class TimParams(ctypes.Structure):
     _fields_ = [("lr", ctypes.c_double), ("temp", ctypes.c_float), ("alpha_value", ctypes.c_float),
                 ("loss_weights", ctypes.c_float * 3), ("entropies", ctypes.c_int32 * 3)]
@@ -24,6 +28,7 @@ _SIGNATURES = {
     "tclip_last_error": (ctypes.c_char_p, []),
     "tclip_workspace_bytes": (ctypes.c_size_t, [ctypes.POINTER(Problem)]),
     "tclip_em_dirichlet_run": (ctypes.c_int, [ctypes.POINTER(Problem)] + [_P] * 10 + [ctypes.c_size_t, _P]),
+    "tclip_em_dirichlet_run_tasks": (ctypes.c_int, [ctypes.POINTER(Problem), ctypes.POINTER(TaskSource)] + [_P] * 8 + [ctypes.c_size_t, _P]),
     "tclip_prototype_workspace_bytes": (ctypes.c_size_t, [ctypes.c_int32] * 3),
     "tclip_cluster_prototypes": (ctypes.c_int, [ctypes.c_int32] * 3 + [_P] * 6 + [ctypes.c_size_t, _P]),
     "tclip_match_clusters_host": (ctypes.c_int, [ctypes.c_int32] * 3 + [_P] * 5 + [ctypes.c_int32, _P, _P]),
@@ -80,7 +85,7 @@ def lib():
         for name, (res, args) in _SIGNATURES.items():
             fn = getattr(l, name)
             fn.restype, fn.argtypes = res, args
-        if l.tclip_abi_version() != 2:
+        if l.tclip_abi_version() != 3:
             raise RuntimeError("libtclip.so ABI version mismatch")
         _lib = l
     return _lib

@@ -93,6 +93,53 @@ def run_em_dirichlet(x_q, x_s=None, y_s=None, *, n_batches=1, iters, iter_mm=100
     return EMDirichletResult(u=u, v=v, alpha=alpha, preds=preds, criterions=crit, mm_iters=mm)
 
 
+def _index_tensor(idx, n_rows, dev, name):
+    """int64 (T,R) index tensor on the device; values are checked on the host when that is where they are (the samplers
+    produce CPU tensors), as torch's own `table[idx]` would raise on an index outside the table"""
+    idx = idx.long()
+    if not idx.is_cuda and idx.numel() and (int(idx.min()) < 0 or int(idx.max()) >= n_rows):
+        raise IndexError(f"{name}: index out of range for a table of {n_rows} rows")
+    return idx.to(dev).contiguous()
+
+
+def run_em_dirichlet_tasks(table_q, q_idx, table_s=None, s_idx=None, y_s=None, cols=None, *, n_batches=1, iters, iter_mm=1000,
+                           lambd, hard=False):
+    """The loop of run_em_dirichlet fed from the task-batch loop's feature tables (tclip_em_dirichlet_run_tasks):
+    table_q (rows,K) f32 cuda, q_idx (T,Q) rows of it; few-shot: table_s, s_idx (T,S), y_s (T,S) the re-indexed support
+    labels; cols (T,K) the per-task column permutation of Tasks_Generator_few_shot.get_task or None.  No (T,S,K) /
+    (T,Q,K) tensor is built; the results are those of run_em_dirichlet on the materialised tensors, bit for bit."""
+    _require_cuda(table_q, "table_q")
+    table_q = table_q.contiguous().float()
+    dev, K = table_q.device, table_q.shape[1]
+    q_idx = _index_tensor(q_idx, table_q.shape[0], dev, "q_idx")
+    T, Q = q_idx.shape
+    if T % n_batches:
+        raise ValueError("number of tasks must be a multiple of n_batches")
+    S = 0
+    if table_s is not None:
+        _require_cuda(table_s, "table_s")
+        table_s = table_s.contiguous().float()
+        s_idx = _index_tensor(s_idx, table_s.shape[0], dev, "s_idx")
+        S = s_idx.shape[1]
+        y_s = y_s.reshape(T, -1).long().to(dev).contiguous()
+        if table_s.shape[1] != K or s_idx.shape[0] != T or tuple(y_s.shape) != (T, S):
+            raise ValueError("table_s must be (rows,K), s_idx and y_s (T,S) with the T of q_idx")
+    if cols is not None:
+        cols = cols.to(torch.int32)
+        if tuple(cols.shape) != (T, K) or (not cols.is_cuda and (int(cols.min()) < 0 or int(cols.max()) >= K)):
+            raise IndexError("cols must be (T,K) with values in [0, K)")
+        cols = cols.to(dev).contiguous()
+    c = _Call(dev, _capi.Problem(n_batches, T // n_batches, Q, K, S, iters, iter_mm, int(lambd), int(bool(hard))), "tclip_workspace_bytes")
+    u, v, alpha, preds = c.empty(T, Q, K), c.empty(T, K), c.empty(T, K, K), c.empty(T, Q, dtype=torch.int32)
+    crit = torch.zeros(n_batches, max(iters, 1), device=dev)[:, :iters].contiguous()
+    mm = torch.zeros(n_batches, max(iters, 1), dtype=torch.int32, device=dev)[:, :iters].contiguous()
+    ptr = lambda t: t.data_ptr() if t is not None else None      # noqa: E731
+    src = _capi.TaskSource(ptr(table_q), ptr(q_idx), ptr(table_s), ptr(s_idx), ptr(cols))
+    c.launch("tclip_em_dirichlet_run_tasks", lambda ws, n, st: (ctypes.byref(src), _ptr(y_s), _ptr(u), _ptr(v), _ptr(alpha),
+                                                                _ptr(preds), _ptr(crit), _ptr(mm), ws, n, st))
+    return EMDirichletResult(u=u, v=v, alpha=alpha, preds=preds, criterions=crit, mm_iters=mm)
+
+
 def run_soft_kmeans(x_q, *, iters, temperature):
     """SOFT_KMEANS: x_q (T,Q,K) f32 cuda -> (u (T,Q,K), w (T,K,K), preds (T,Q) i32), cuda, not synchronised."""
     x_q = _query(x_q)
