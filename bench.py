@@ -57,6 +57,7 @@ sys.path.insert(0, os.path.join(ROOT, "transductive-clip_amd"))
 sys.path.insert(0, os.path.join(ROOT, "transductive-clip_amd", "drop_in"))
 
 import torch  # noqa: E402
+from tclip_amd import _capi  # noqa: E402
 
 N_QUERY = 75
 ITERS = 20
@@ -198,6 +199,12 @@ def roofline_of(prof, steps, K, pmc_key):
            "hbm": {"bound": "hbm", "achieved": hbm_gbs, "peak": PEAK_HBM_GBS, "unit": "GB/s",
                    "frac": hbm_gbs / PEAK_HBM_GBS, "algorithmic_bytes_per_step": rows_bytes / steps}}
     pmc = load_pmc()
+    if pmc and pmc_key in pmc and pmc[pmc_key].get("csrc_sha1") != _capi.source_digest():
+        # the committed counters were taken on other kernel sources: traffic, clock and the fractions derived from them
+        # would describe a build that no longer exists
+        out["pmc_stale"] = {"file": pmc[pmc_key].get("file"), "commit": pmc[pmc_key].get("commit"),
+                            "note": "csrc changed since this PMC pass: traffic / measured_clock_ghz not reported"}
+        pmc = None
     if pmc and pmc_key in pmc:
         e = pmc[pmc_key]
         # traffic and the algorithmic bytes it is to be compared with come from the SAME (smaller) PMC workload
@@ -248,13 +255,19 @@ def main():
             dist.init_process_group("nccl", device_id=dev)
         else:
             dist.init_process_group(args.backend)
+        if dist.get_world_size() != args.gpus:
+            raise SystemExit(f"--gpus {args.gpus} but the launcher started {dist.get_world_size()} ranks")
 
     import random
 
     import numpy as np
     from src.eval_zero_shot import Evaluator_zero_shot
     from src.utils import CfgNode
-    from tclip_amd import engine, synth
+    from tclip_amd import engine, sharding, synth
+
+    rank_devices = None
+    if dist_on and not args.single_device:               # one GPU per rank, or the per-N values would not be a scaling curve
+        rank_devices = sharding.check_one_device_per_rank(torch.cuda.current_device(), dev if args.backend == "nccl" else None)
 
     def fence():
         if dist_on:
@@ -287,14 +300,8 @@ def main():
         elapsed = time.perf_counter() - t0
         prof = engine.profile_collect()
         engine.profile_enable(False)
-        per_rank = [elapsed]
-        if dist_on:
-            where = dev if args.backend == "nccl" else "cpu"
-            mine = torch.tensor([elapsed], device=where, dtype=torch.float64)
-            every = [torch.zeros_like(mine) for _ in range(world)]
-            dist.all_gather(every, mine)
-            per_rank = [float(t.item()) for t in every]
-            elapsed = max(per_rank)                      # the job is done when its slowest rank is
+        per_rank = sharding.gather_rank_values(elapsed, dev if args.backend == "nccl" else None) if dist_on else [elapsed]
+        elapsed = max(per_rank)                          # the job is done when its slowest rank is
         return elapsed, prof, res, per_rank
 
     def run_steps(ev, table, labels, idx, warmup, steps):
@@ -424,6 +431,7 @@ def main():
         }
         if dist_on:
             line["ranks_seen"] = dist.get_world_size()
+            line["rank_devices"] = rank_devices
             line["backend"] = dist.get_backend()
             line["rank_step_ms"] = {"min": 1e3 * min(per_rank) / steps, "max": 1e3 * max(per_rank) / steps,
                                     "all": [1e3 * t / steps for t in per_rank]}

@@ -125,6 +125,10 @@ int tclip_match_clusters_host_strided(int32_t n_task, int32_t n_query, int32_t n
                                       const int64_t* y_q, int32_t graph_matching, int32_t c_stride, int32_t* new_preds,
                                       float* acc);
 
+/* Host threads tclip_match_clusters_host* may start: TCLIP_HOST_THREADS if set, else min(16, cores this process may run
+ * on / LOCAL_WORLD_SIZE) - one process per GPU must not oversubscribe the node's cores. */
+int tclip_host_threads(void);
+
 /* Task construction for the task-batch loop (eval_zero_shot.py:160-168): gathers rows of a
  * device-resident feature table.  table device [n_rows, K] f32, idx device [n_out] i64,
  * out device [n_out, K] f32. */
@@ -285,6 +289,12 @@ int tclip_debug_set_rowset_min_rows(int32_t rows);
  * the first iteration on, 100 + n from outer iteration n on, negative restores the default rule (n = 1).  Process-wide;
  * results do not depend on it. */
 int tclip_debug_set_mm_split(int32_t mode);
+
+/* The squared distances of the k-means family (SOFT/HARD_KMEANS, EM_GAUSSIAN, PADDLE, BD-CSPN) run one lane per class on a
+ * 64-centroid tile staged in LDS for rows of 32 .. 511 elements (k_kmeans_logits_tile), 32 lanes per class otherwise.  For
+ * tests: 0 uses the 32-lane kernel for every row length, negative restores the default rule.  Process-wide; results do not
+ * depend on it. */
+int tclip_debug_set_kmeans_tile(int32_t mode);
 
 /* Device self-test (used by tests/test_gpu_primitives.py).  out host [14]:
  *   [0] 1/x: fast exact reciprocal vs IEEE quotient, every float of a binade at 3 exponents

@@ -4,6 +4,9 @@ bench.py reads for roofline.traffic, and keeps per-round copies under profiles/.
 import json, os, subprocess, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 tag = sys.argv[1] if len(sys.argv) > 1 else "r02"
+sys.path.insert(0, os.path.join(ROOT, "transductive-clip_amd"))
+from tclip_amd import _capi  # noqa: E402
+digest = _capi.source_digest()          # the kernel sources the counters were taken on (bench.py nulls stale PMC fields)
 commit = subprocess.run(["git", "rev-parse", "--short", "HEAD"], cwd=ROOT, capture_output=True, text=True).stdout.strip()
 out = {}
 for key in ("k1000", "k100", "k397_hard", "fs_k1000"):
@@ -15,6 +18,7 @@ for key in ("k1000", "k100", "k397_hard", "fs_k1000"):
     s = d["summary"]
     s["file"] = f"profiles/{tag}_pmc_{key}.json"
     s["commit"] = commit
+    s["csrc_sha1"] = digest
     out[key] = s
 json.dump(out, open(os.path.join(ROOT, "profiles", "pmc_current.json"), "w"), indent=1)
 print(json.dumps({k: {f: v[f] for f in ("lane_instr_per_update", "wait_frac", "traffic_bytes_per_launch", "algorithmic_bytes_per_launch")} for k, v in out.items()}, indent=1))

@@ -24,3 +24,24 @@ def test_bigbatch_fixture_inputs_and_first_iteration():
     assert ref["mm_iters"][0] == g["mm_iters"][0]
     assert np.array_equal(ref["argmax"][0], g["argmax"][0])
     assert ref["criterions"][0] == g["criterions"][0]
+
+
+def test_round4_bigbatch_fixtures_inputs_are_reproducible():
+    """the two lean fixtures of round 4 (HARD at K = 397, FEW-SHOT at K = 100; both over 16 384 rows): the integer
+    generator returns their inputs bit for bit on this host, the recorded MM counts have the reference's pattern, and the
+    hard one contains an early stop decided over the whole 16 674-row batch.  (The schedules themselves are the GPU
+    tests' job, tests/test_gpu_round4.py.)"""
+    sha = lambda a: hashlib.sha1(np.ascontiguousarray(a).tobytes()).hexdigest()      # noqa: E731
+    g = np.load(os.path.join(GOLDEN, "bigbatch_zs_hard_K397_N42.npz"))
+    K, N = int(g["K"]), int(g["N"])
+    assert N * K > 16384 and str(g["kind"]) == "zs_hard" and str(g["inputs"]) == "intsynth"
+    x_q, y_q = intsynth.make_tasks(int(g["seed"]), N, K, 75, boost=int(g["boost"]))
+    assert sha(x_q) == str(g["x_q_sha1"]) and np.array_equal(y_q, g["y_q"].reshape(N, 75))
+    assert g["mm_iters"].tolist() == [101] + [1000] * 9
+    g = np.load(os.path.join(GOLDEN, "bigbatch_fs_soft_K100_N170_s1.npz"))
+    K, N = int(g["K"]), int(g["N"])
+    assert N * K > 16384 and str(g["kind"]) == "fs_soft" and int(g["shots"]) == 1
+    x_q, y_q, x_s, y_s = intsynth.make_tasks(int(g["seed"]), N, K, 75, shots=1, boost=int(g["boost"]))
+    assert sha(x_q) == str(g["x_q_sha1"]) and sha(x_s) == str(g["x_s_sha1"])
+    assert np.array_equal(y_q, g["y_q"].reshape(N, 75)) and np.array_equal(y_s, g["y_s"].reshape(N, K))
+    assert (g["mm_iters"] == 1000).all()            # 20 x 19 recorded decisions not to stop, each over 17 000 rows

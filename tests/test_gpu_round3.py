@@ -162,7 +162,7 @@ def test_class_split_kernel_with_nan_and_stopped_batches(K, N, iter_mm):
     from tclip_amd import engine, synth
     B = 2
     x_q, _ = synth.make_query_tasks(B * N, K, seed=8300 + K)
-    # batch 1: nearly flat features - its MM loop stops at an early checkpoint while batch 0 runs on
+    # batch 1: nearly flat features - its MM loop never converges within iter_mm, batch 0's first one stops early
     x_q[N:] = torch.softmax(torch.log(x_q[N:]) * 0.02, -1)
     x_bad = x_q.clone()
     x_bad[1, 3, 5] = float("nan")
@@ -179,7 +179,9 @@ def test_class_split_kernel_with_nan_and_stopped_batches(K, N, iter_mm):
     assert any("k_mm_split" in n for n in names[1]), names[1]
     assert not any("k_mm_split" in n for n in names[0]), names[0]
     clean = out[0][0].mm_iters.cpu().numpy()
-    assert (clean[1] < iter_mm).any() and (clean[0] > clean[1]).any(), f"batch 1 should stop before batch 0: {clean.tolist()}"
+    # some outer iteration in which one batch stops at a checkpoint while the other runs on (measured: batch 0 stops at MM
+    # iteration 151 / 201 of the first outer iteration, the flat batch 1 never stops) - in mode 1 that iteration runs k_mm_split
+    assert ((clean[0] < iter_mm) & (clean[1] == iter_mm)).any(), f"one batch should stop while the other runs on: {clean.tolist()}"
     assert torch.isnan(out[0][1].alpha[1]).any(), "the NaN feature must reach alpha (the generic path ran)"
     for a, b in zip(out[0], out[1]):
         for name in ("alpha", "u", "v", "preds", "mm_iters"):

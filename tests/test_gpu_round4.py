@@ -90,7 +90,7 @@ def test_headline_batch_k1000_full_schedule():
     acc, matched = engine.clustering_accuracy(x, res.preds, y)
     assert np.array_equal(acc.numpy().reshape(N), ev.last_task_accuracies[0])
     assert np.array_equal(matched.cpu().numpy().reshape(N, 75), ev.last_task_predictions[0])
-    assert abs(float(acc.mean()) - float(acc_mean)) < 1e-6 and 0.5 < float(acc_mean) <= 1.0
+    assert abs(float(acc.mean()) - float(acc_mean)) < 1e-6 and 0.2 < float(acc_mean) <= 1.0     # chance level: 0.001 (the bench's table gives 0.44)
 
 
 def test_configs2_batch_hard_k397_and_soft_kmeans():
@@ -124,7 +124,7 @@ def test_configs2_batch_hard_k397_and_soft_kmeans():
     # with one-hot u the cluster sizes are counts: v = log(count/75 + eps) + 1 exactly as fp32 evaluates it for integers
     counts = res.u.sum(1)
     assert torch.equal(counts, counts.round()) and (counts.sum(-1) == 75).all()
-    assert 0.5 < float(acc_hard) <= 1.0
+    assert 0.2 < float(acc_hard) <= 1.0                    # chance level: 1/397
     # SOFT_KMEANS on the same tasks
     ev2 = Evaluator_zero_shot(device=torch.device(DEV), log_file=None, args=CfgNode(dict(cfg, name_method="SOFT_KMEANS", iter=20)))
     acc_skm, _ = ev2.evaluate_tasks(None, table, labels, indices=idx)
@@ -135,7 +135,7 @@ def test_configs2_batch_hard_k397_and_soft_kmeans():
     assert torch.equal(ev2.last_method.u, u) and torch.equal(ev2.last_method.w, w)
     assert (u >= 0).all() and (u.sum(-1) - 1).abs().max() <= 1e-5 and torch.isfinite(w).all()
     assert torch.equal(preds.long(), u.argmax(-1))
-    assert 0.3 < float(acc_skm) <= 1.0
+    assert 0.1 < float(acc_skm) <= 1.0                     # chance level: 1/397 (the bench's table gives 0.22)
     # first task against the C++ oracle's SOFT_KMEANS (397 x 397 x 75 x 20 on the host is seconds)
     from oracle import c_oracle
     ref = c_oracle.run_soft_kmeans(x[:1].cpu().numpy(), iters=20, temperature=30)
@@ -193,7 +193,7 @@ def test_configs4_batch_few_shot_k1000_s4000():
     assert (res.u >= 0).all() and (res.u.sum(-1) - 1).abs().max() <= 1e-5
     acc = (res.preds.cpu().long() == y_q).float().mean(1)
     assert np.array_equal(acc.numpy(), ev.last_task_accuracies[0]) and abs(float(acc.mean()) - float(acc_mean)) < 1e-6
-    assert float(acc_mean) > 0.5
+    assert float(acc_mean) > 0.2
     del x_s
     again, _ = ev.evaluate_tasks(None, tab_s, lab_s, tab_q, lab_q, indices=(s_idx, q_idx))
     assert again == acc_mean and torch.equal(ev.last_method.alpha, res.alpha)           # run-to-run
@@ -337,3 +337,34 @@ def test_table_fed_entry_equals_materialised_tensors(K, N, B, shots, perm, hard)
         assert torch.equal(getattr(ref, name), getattr(got, name)), name
     with pytest.raises(IndexError):
         engine.run_em_dirichlet_tasks(tq, q_idx + tab_q.shape[0], ts, s_idx, y_s, cols, **kw)
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("K", [32, 33, 40, 47, 63, 64, 65, 96, 100, 127, 128, 129, 196, 255, 256, 257, 397, 448, 449, 511])
+def test_kmeans_tile_kernel_is_invisible(K):
+    """k_kmeans_logits_tile (one lane per class on a 64-centroid LDS tile, rows of 32 .. 511 elements) against
+    k_kmeans_logits_rows (32 lanes per class) through SOFT_KMEANS, HARD_KMEANS and PADDLE: identical u, centroids and
+    predictions - row lengths with every K mod 32 structure (no / one / three leftover vectors, tails of 0 .. 7, the tile
+    edges 64 k and 64 k + 1); the smaller ones also against the C++ oracle."""
+    from oracle import c_oracle
+    from tclip_amd import _capi, engine, synth
+    N = 3
+    x_q, _ = synth.make_query_tasks(N, K, seed=6000 + K)
+    x_s, y_s = synth.make_support(N, K, 1, seed=6100 + K)
+    x, xs, ys = x_q.to(DEV), x_s.to(DEV), y_s.squeeze(2).to(DEV)
+    out = {}
+    try:
+        for mode in (0, -1):
+            _capi.check(_capi.lib().tclip_debug_set_kmeans_tile(mode), "tclip_debug_set_kmeans_tile")
+            out[mode] = (engine.run_soft_kmeans(x, iters=6, temperature=30), engine.run_hard_kmeans(x, iters=4),
+                         engine.run_paddle(x, xs, ys, iters=5, lambd=2.5))
+            torch.cuda.synchronize()
+    finally:
+        _capi.lib().tclip_debug_set_kmeans_tile(-1)
+    for a, b in zip(out[0], out[-1]):
+        for ta, tb in zip(a, b):
+            assert torch.equal(ta, tb)
+    if K <= 128:
+        ref = c_oracle.run_soft_kmeans(x_q.numpy(), iters=6, temperature=30)
+        u, w, _ = out[-1][0]
+        assert np.array_equal(u.cpu().numpy(), ref["u"]) and np.array_equal(w.cpu().numpy(), ref["w"])

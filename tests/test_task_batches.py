@@ -187,3 +187,73 @@ def test_relabel_indices_equals_get_task_relabelling():
     y_missing = y_s.clone()
     y_missing[2][y_missing[2] == 3] = 4
     assert relabel_indices(y_missing, y_q, K) is None
+
+
+def _worker_eight(rank, world, port, out):
+    """configs[3] as the 8-GPU bench runs it, minus the GPUs: 80 batches of 125 tasks dealt to 8 ranks, every rank hands its
+    10 batches' records to the ONE packed all_gather; the ranks' step times and device indices travel as the bench moves
+    them (sharding.gather_rank_values / check_one_device_per_rank)."""
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    n_batches, N, Q, iters = 80, 125, 75, 20
+    mine = sharding.my_batches(n_batches)
+    assert len(mine) == 10 and mine[0] == rank
+    calls = []
+    real = dist.all_gather
+    dist.all_gather = lambda *a, **k: (calls.append(1), real(*a, **k))[1]
+    parts = {"preds": torch.stack([torch.full((N * Q,), b, dtype=torch.int32) for b in mine]),
+             "acc": torch.stack([torch.full((N,), b / 100.0) for b in mine]),
+             "criterions": torch.stack([torch.full((iters,), b * 1e-3) for b in mine]),
+             "mm_iters": torch.stack([torch.full((iters,), 51 + b, dtype=torch.int32) for b in mine])}
+    got = sharding.gather_packed(parts, n_batches)
+    assert len(calls) == 1, "exactly one collective per step"
+    dist.all_gather = real
+    secs = sharding.gather_rank_values(9.0 + 0.01 * rank)              # every rank sees every rank's time
+    assert len(secs) == world and max(secs) == pytest.approx(9.07) and min(secs) == pytest.approx(9.0)
+    assert sharding.check_one_device_per_rank(rank) == list(range(world))
+    try:
+        sharding.check_one_device_per_rank(0)                          # every rank on cuda:0: must be refused
+        shared_refused = False
+    except RuntimeError:
+        shared_refused = True
+    assert shared_refused
+    if rank == 0:
+        torch.save({"got": got, "secs": secs}, out)
+    else:
+        assert got is None
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_eight_ranks_gather_configs3_records_gloo(tmp_path):
+    """world size 8 (one process per GPU of a node), the shapes of the bench line's `config.gathered` and `rank_step_ms`"""
+    out = str(tmp_path / "eight.pt")
+    mp.spawn(_worker_eight, args=(8, 29500 + ((os.getpid() + 1543) % 2000), out), nprocs=8, join=True)
+    r = torch.load(out)
+    got = r["got"]
+    assert tuple(got["preds"].view(80, 125, 75).shape) == (80, 125, 75) and got["preds"].dtype == torch.int32
+    assert tuple(got["criterions"].shape) == (80, 20) and tuple(got["mm_iters"].shape) == (80, 20) and tuple(got["acc"].shape) == (80, 125)
+    for b in range(80):                                                # batch order restored from the round-robin deal
+        assert int(got["preds"][b, 0]) == b and int(got["mm_iters"][b, 0]) == 51 + b
+        assert float(got["acc"][b, 0]) == np.float32(b / 100.0) and float(got["criterions"][b, 0]) == np.float32(b * 1e-3)
+    secs = r["secs"]
+    skew = (max(secs) - min(secs)) / max(secs)
+    assert len(secs) == 8 and 0 < skew < 0.01
+
+
+def test_host_thread_cap_respects_local_world_size(monkeypatch):
+    """tclip_host_threads: min(16, cores / LOCAL_WORLD_SIZE), TCLIP_HOST_THREADS wins"""
+    import subprocess
+    import sys
+    from conftest import PKG
+    code = "import sys; sys.path.insert(0, %r); from tclip_amd import _capi; print(_capi.lib().tclip_host_threads())" % PKG
+    cores = len(os.sched_getaffinity(0))
+
+    def run(**env):
+        e = {k: v for k, v in os.environ.items() if k not in ("LOCAL_WORLD_SIZE", "TCLIP_HOST_THREADS")}
+        e.update(env)
+        return int(subprocess.run([sys.executable, "-c", code], env=e, capture_output=True, text=True, check=True).stdout.strip())
+    assert run() == min(16, cores)
+    assert run(LOCAL_WORLD_SIZE="8") == max(1, min(16, cores // 8))
+    assert run(LOCAL_WORLD_SIZE="2") == max(1, min(16, cores // 2))
+    assert run(LOCAL_WORLD_SIZE="8", TCLIP_HOST_THREADS="5") == 5

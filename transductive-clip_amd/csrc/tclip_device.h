@@ -107,7 +107,10 @@ __device__ __forceinline__ float group_sum_torch(const float (&x)[E], int K, int
 // Element d lives in register d / G of lane d % G.  With H = G / 8 lanes-of-eight per group, lane (h, j) =
 // 8 h + j holds the 8-float vector v = e H + h in register e; torch's accumulator r = v % 4 and step m = v / 4
 // are r = (e % P) H + h, m = e / P with P = 4 / H registers per step, so a lane keeps P partial sums.
-template <int E, int G, bool kLane0 = false>
+// kSure: the caller guarantees that registers below it hold steps of the 4-way interleaved part (e / P < K / 32) for every K
+// the instantiation is used for, which frees their additions from the per-register tests (wave-uniform, but K is a run-time
+// value: the compiler kept 2 E lane masks in scalar registers, spilled them, and read them back every iteration).
+template <int E, int G, bool kLane0 = false, int kSure = 0>
 __device__ __forceinline__ float group_sum_torch_g(const float (&x)[E], int K, int lane) {
     static_assert(G == 8 || G == 16, "lanes per row");
     constexpr int H = G / 8, P = 4 / H;
@@ -136,8 +139,12 @@ __device__ __forceinline__ float group_sum_torch_g(const float (&x)[E], int K, i
 #pragma unroll
             for (int q = 0; q < P; q++) { a1[q] += a0[q]; a0[q] = 0.0f; }
         }
-        if (m < size_ilp) a0[p] += x[e];
-        if (m == size_ilp) rag[p] = x[e];
+        if (e < kSure) {
+            a0[p] += x[e];
+        } else {
+            if (m < size_ilp) a0[p] += x[e];
+            if (m == size_ilp) rag[p] = x[e];
+        }
     }
     float pm[P];
 #pragma unroll
@@ -175,7 +182,9 @@ __device__ __forceinline__ float group_sum_torch_g(const float (&x)[E], int K, i
 // 512 q + 32 e + l in register e (E = 16).  torch's 4-way interleaved accumulators dump their running sums
 // every 16 steps, so accumulator (l / 8, l % 8) is RN(sum of steps 0..15) + RN(sum of steps 16..) - the two
 // halves of the wavefront build the two terms independently.  Valid in all 64 lanes.
-template <int E, bool kLane0 = false>
+// kSure: registers below it are steps of the interleaved part in BOTH halves for every K of the instantiation
+// (16 + e < K / 32), see group_sum_torch_g.
+template <int E, bool kLane0 = false, int kSure = 0>
 __device__ __forceinline__ float group_sum_torch_64(const float (&x)[E], int K, int lane) {
     static_assert(E == 16, "two halves of 16 steps");
     const int vec_size = K >> 3, size_ilp = vec_size >> 2;       // 16 <= size_ilp <= 32
@@ -184,8 +193,12 @@ __device__ __forceinline__ float group_sum_torch_64(const float (&x)[E], int K, 
 #pragma unroll
     for (int e = 0; e < E; e++) {
         const int m = e + 16 * q;
-        if (m < size_ilp) acc += x[e];
-        if (m == size_ilp) ragged = x[e];
+        if (e < kSure) {
+            acc += x[e];
+        } else {
+            if (m < size_ilp) acc += x[e];
+            if (m == size_ilp) ragged = x[e];
+        }
     }
     const float pm = acc + __shfl_xor(acc, 32, 64);               // a0 + a1 (either order: one addition)
     const int rq = (size_ilp >> 4) * 32;                           // the half that holds the ragged step

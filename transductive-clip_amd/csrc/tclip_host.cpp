@@ -14,6 +14,7 @@
 #include <stdlib.h>
 
 #include <algorithm>
+#include <sched.h>
 #include <thread>
 #include <vector>
 
@@ -132,8 +133,26 @@ int match_range(int t0, int t1, int Q, int K, int Cmax, const int32_t* preds, co
 
 }  // namespace
 
+// Host threads for the matching: TCLIP_HOST_THREADS if set, else up to 16 but no more than this process's share of the
+// cores it may run on - the affinity mask divided by LOCAL_WORLD_SIZE (set by torch.distributed.run: one process per
+// GPU, eight of them on a node would otherwise start 8 x 16 threads at the same moment of every step).
+static int host_thread_cap() {
+    if (const char* e = getenv("TCLIP_HOST_THREADS")) return atoi(e) > 0 ? atoi(e) : 1;
+    int cores = 0;
+    cpu_set_t set;
+    if (sched_getaffinity(0, sizeof set, &set) == 0) cores = CPU_COUNT(&set);
+    if (cores <= 0) cores = (int)std::thread::hardware_concurrency();
+    if (cores <= 0) cores = 1;
+    int ranks = 1;
+    if (const char* e = getenv("LOCAL_WORLD_SIZE")) ranks = atoi(e) > 0 ? atoi(e) : 1;
+    int n = cores / ranks;
+    if (n > 16) n = 16;
+    return n < 1 ? 1 : n;
+}
+extern "C" int tclip_host_threads(void) { return host_thread_cap(); }
+
 // Tasks are independent: large batches are matched by a few host threads (the K = 1000 bench step spent 150 ms
-// here on one thread, 1.2 % of the step).  TCLIP_HOST_THREADS overrides the count (default: up to 16).
+// here on one thread, 1.2 % of the step).
 extern "C" int tclip_match_clusters_host_strided(int32_t T, int32_t Q, int32_t K, const int32_t* preds,
                                                  const int32_t* n_clusters, const int32_t* cluster_ids,
                                                  const float* prototypes, const int64_t* y_q, int32_t graph_matching,
@@ -142,10 +161,7 @@ extern "C" int tclip_match_clusters_host_strided(int32_t T, int32_t Q, int32_t K
         return TCLIP_ERR_ARG;
     const int Cmax = c_stride;
     if (Cmax < 1 || Cmax > (Q < K ? Q : K)) return TCLIP_ERR_ARG;
-    int n_threads = 16;
-    if (const char* e = getenv("TCLIP_HOST_THREADS")) n_threads = atoi(e);
-    const int hw = (int)std::thread::hardware_concurrency();
-    if (hw > 0 && n_threads > hw) n_threads = hw;
+    int n_threads = host_thread_cap();
     const long work = (long)T * K;                             // below ~8 k cost-matrix columns per thread a thread is not worth starting
     if (n_threads > work / 8192) n_threads = (int)(work / 8192);
     if (n_threads > T) n_threads = T;

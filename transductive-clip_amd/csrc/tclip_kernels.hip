@@ -39,6 +39,11 @@
 #include "tclip_pk.h"
 #include "tclip_selftest_inputs.h"
 
+#ifndef TCLIP_G64_MIN_K
+#define TCLIP_G64_MIN_K 897           // rows from this length on: one wavefront per row, 16 registers per lane instead of 32 lanes x 32
+                                      // registers (half the code, 4 instead of 3 wavefronts per SIMD): K = 1000 bench shape 12.55 -> 11.90 s
+#endif
+
 namespace tclip {
 
 // ------------------------------------------------------------------------------------------
@@ -582,12 +587,21 @@ __device__ __forceinline__ void mm_apply_updates(float (&beta)[E], const RowY<E,
     }
 }
 
+// Registers of an MM kernel instantiation that lie inside the row - and inside the 4-way interleaved part of torch's row
+// sum - for EVERY row length the instantiation is launched for (launch_mm: the smallest E that covers K, so at most
+// three registers of slack, the fourth for the upper half of the 64-lane layout, which starts at K = 897).
+template <int E, int G>
+constexpr int sure_registers() {
+    if (G == 64) return (TCLIP_G64_MIN_K >= 897 && E == 16) ? 12 : 0;      // 16 + e < K / 32 for K >= 897
+    return E > 4 ? E - 4 : 0;
+}
+
 // the row sum in torch's order, valid in every lane of the row's lane group
 template <int E, int G>
 __device__ __forceinline__ float row_sum_torch_all(const float (&x)[E], int K, int lane) {
-    if constexpr (G == kGroup) return group_sum_torch<E>(x, K, lane);
-    else if constexpr (G == 64) return group_sum_torch_64<E>(x, K, lane);
-    else return group_sum_torch_g<E, G>(x, K, lane);
+    if constexpr (G == kGroup) return group_sum_torch<E, false, sure_registers<E, G>()>(x, K, lane);
+    else if constexpr (G == 64) return group_sum_torch_64<E, false, sure_registers<E, G>()>(x, K, lane);
+    else return group_sum_torch_g<E, G, false, sure_registers<E, G>()>(x, K, lane);
 }
 
 template <int E, int G>
@@ -743,9 +757,9 @@ struct QueueCtl { int count[2][8]; int bad; float rowsum[2][64]; float psi[2][64
 // the row sum in torch's order, valid in lane 0 of the row's lane group (K >= 8; shorter rows: in every lane)
 template <int E, int G>
 __device__ __forceinline__ float row_sum_torch(const float (&x)[E], int K, int lane) {
-    if constexpr (G == kGroup) return group_sum_torch<E, true>(x, K, lane);
-    else if constexpr (G == 64) return group_sum_torch_64<E, true>(x, K, lane);
-    else return group_sum_torch_g<E, G, true>(x, K, lane);
+    if constexpr (G == kGroup) return group_sum_torch<E, true, sure_registers<E, G>()>(x, K, lane);
+    else if constexpr (G == 64) return group_sum_torch_64<E, true, sure_registers<E, G>()>(x, K, lane);
+    else return group_sum_torch_g<E, G, true, sure_registers<E, G>()>(x, K, lane);
 }
 
 template <int E, int W, int R, int G>
@@ -1509,6 +1523,80 @@ __global__ __launch_bounds__(256) void k_kmeans_logits_rows(const float* __restr
         }
     }
 }
+
+// The same logits with the roles turned round (round 4): ONE LANE per class, the whole sum over d inside the lane.
+// k_kmeans_logits_rows spreads a (query, class) pair over 32 lanes and pays ~25 cross-lane instructions (shuffles through
+// the LDS crossbar, DPP adds) beside the 39 arithmetic ones for every 397-element sum, reads each query row once per four
+// classes from L2, and stores one float per 32 lanes.  Here a block stages a tile of 64 centroids in LDS once (odd row
+// stride: lane k reads word k stride + d, 32 lanes on 32 banks), lane k of every wavefront keeps torch's 32 partial sums
+// (accumulator r = 0..3, vector lane j = 0..7: element d = 32 m + 8 r + j belongs to slot 8 r + j at step m) in registers,
+// the wavefront's query row is wave-uniform and arrives through the scalar cache as the SGPR operand of the subtraction:
+// three VALU instructions and one ds_read per (query, class, d), nothing across lanes, coalesced stores.  Same operations
+// in the same order as group_sum_torch (slots sequentially over the steps, whole vectors beyond the 4-way part into
+// accumulator 0, a0 + a1 + a2 + a3 per vector lane, the K mod 8 tail first, then the eight vector lanes), hence the same
+// bits: tests/test_gpu_round4.py::test_kmeans_tile_kernel_is_invisible runs both kernels on 20 row lengths.
+// Rows of 32 .. 511 elements (fewer than 16 steps: torch's cascade never dumps; 64 x 511 floats of LDS = 131 KB).
+constexpr int kKmeansTile = 64;
+#ifndef TCLIP_KMEANS_TILE_THREADS
+#define TCLIP_KMEANS_TILE_THREADS 512     // the tile's LDS (101 KB at K = 397) allows one block per CU: eight wavefronts share it, two per SIMD
+#endif
+constexpr int kKmeansTileThreads = TCLIP_KMEANS_TILE_THREADS;
+__global__ __launch_bounds__(512) void k_kmeans_logits_tile(const float* __restrict__ w, const float* __restrict__ z,
+                                                            const uint8_t* __restrict__ need, int Q, int K, int stride, float pre,
+                                                            float temperature, float* __restrict__ logit0) {
+    extern __shared__ float wt[];                                   // [kKmeansTile][stride]
+    const int t = blockIdx.y, k0 = blockIdx.x * kKmeansTile;
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), n_waves = blockDim.x >> 6;
+    const int k = k0 + lane;
+    const bool ok = k < K && need[(size_t)t * K + k];
+    if (!__syncthreads_or(ok)) return;                              // no class of the tile moved
+    const int rows = K - k0 < kKmeansTile ? K - k0 : kKmeansTile;
+    const float* wsrc = w + ((size_t)t * K + k0) * K;
+    for (int i = threadIdx.x; i < rows * K; i += blockDim.x) {
+        const int r = i / K;
+        wt[r * stride + (i - r * K)] = wsrc[i];
+    }
+    __syncthreads();
+    const float* wl = wt + (lane < rows ? lane : rows - 1) * stride;     // lanes beyond the last class recompute it; nothing is stored
+    const int vec_size = K >> 3, size_ilp = vec_size >> 2, nleft = vec_size - 4 * size_ilp, ntail = K - 8 * vec_size;
+    for (int q = wave; q < Q; q += n_waves) {
+        const float* zq = z + ((size_t)t * Q + q) * K;              // wave-uniform: scalar loads
+        float acc[32];
+#pragma unroll
+        for (int sl = 0; sl < 32; sl++) acc[sl] = 0.0f;
+        for (int m = 0; m < size_ilp; m++) {
+#pragma unroll
+            for (int sl = 0; sl < 32; sl++) {
+                const float df = wl[32 * m + sl] - zq[32 * m + sl];
+                acc[sl] += df * df;
+            }
+        }
+        int d = 32 * size_ilp;
+        for (int i = 0; i < nleft; i++, d += 8) {                   // whole vectors beyond the 4-way part join accumulator 0
+#pragma unroll
+            for (int j = 0; j < 8; j++) {
+                const float df = wl[d + j] - zq[d + j];
+                acc[j] += df * df;
+            }
+        }
+        float fin = 0.0f;
+        for (int i = 0; i < ntail; i++) {                           // the K mod 8 tail first
+            const float df = wl[d + i] - zq[d + i];
+            fin += df * df;
+        }
+#pragma unroll
+        for (int j = 0; j < 8; j++) {
+            float p0 = acc[j];
+            p0 += acc[8 + j];
+            p0 += acc[16 + j];
+            p0 += acc[24 + j];
+            fin += p0;
+        }
+        if (ok) logit0[((size_t)t * Q + q) * K + k] = temperature * (pre * fin);
+    }
+}
+
 
 // EM_GAUSSIAN_COV E-step (em_gaussian_cov.py:106-129):
 //   logit[t,q,k] = -1/2 sum_d ((w[t,k,d] - z[t,q,d])^2 * s[t,k,d]) + 1/2 sum_d log(s[t,k,d] + eps),
@@ -2319,10 +2407,6 @@ static void dispatch_E(int K, Args... args) {
 #ifndef TCLIP_G16_MAX_K
 #define TCLIP_G16_MAX_K 256
 #endif
-#ifndef TCLIP_G64_MIN_K
-#define TCLIP_G64_MIN_K 897           // rows from this length on: one wavefront per row, 16 registers per lane instead of 32 lanes x 32
-                                      // registers (half the code, 4 instead of 3 wavefronts per SIMD): K = 1000 bench shape 12.55 -> 11.90 s
-#endif
 #ifndef TCLIP_MM_LAUNCH_WAVES
 #define TCLIP_MM_LAUNCH_WAVES 4
 #endif
@@ -2415,6 +2499,26 @@ template <int E> struct LaunchKmeansLogitsRows {
                            pre, temperature, logit0);
     }
 };
+
+static int g_kmeans_tile = -1;       // tclip_debug_set_kmeans_tile: 0 = k_kmeans_logits_rows for every K, negative: the default rule
+// squared distances to the centroids: one lane per class where the row length allows it (k_kmeans_logits_tile), else 32 lanes per class
+static void launch_kmeans_logits(int T, hipStream_t st, const float* w, const float* z, const uint8_t* need, int Q, int K, float pre,
+                                 float temperature, float* logit0) {
+    if (g_kmeans_tile != 0 && K >= 32 && K <= 511) {
+        const int stride = K | 1;
+        const size_t lds = (size_t)kKmeansTile * stride * sizeof(float);
+        static const bool raised = [] {                               // beyond the 64 KB a kernel gets without asking
+            return hipFuncSetAttribute((const void*)k_kmeans_logits_tile, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                       kKmeansTile * 511 * (int)sizeof(float)) == hipSuccess;
+        }();
+        if (raised) {
+            hipLaunchKernelGGL(k_kmeans_logits_tile, dim3((K + kKmeansTile - 1) / kKmeansTile, T), dim3(kKmeansTileThreads), lds, st, w, z, need, Q, K,
+                               stride, pre, temperature, logit0);
+            return;
+        }
+    }
+    dispatch_E<LaunchKmeansLogitsRows>(K, T, st, w, z, need, Q, K, pre, temperature, logit0);
+}
 
 // M-step statistics / centroids / prototypes: rows whose K columns all lie in torch's cascade region
 // go through the 8-rows-per-thread kernel, the last few rows through the one-row kernel.
@@ -2817,7 +2921,7 @@ static int soft_kmeans_core(const tclip_problem& p, const float* x_q, float temp
                            live, it > 0 ? v : (float*)nullptr, (int32_t*)nullptr);
         launch_mstats(st, (const float*)u, (const float*)x_q, (const float*)cs, (const uint8_t*)live, (const float*)nullptr, (const float*)nullptr, T, Q, K, w, 0);
         // distances only for centroids that moved (all of them in the first iteration)
-        dispatch_E<LaunchKmeansLogitsRows>(K, T, st, (const float*)w, x_q, (const uint8_t*)(it == 0 ? ones : live), Q, K, -0.5f,
+        launch_kmeans_logits(T, st, (const float*)w, x_q, (const uint8_t*)(it == 0 ? ones : live), Q, K, -0.5f,
                                            temperature, logit0);
         hipLaunchKernelGGL(k_softmax, dim3((T * Q * 16 + 255) / 256), dim3(256), 0, st, (const float*)logit0,
                            (const float*)v, T * Q, Q, K, (float)p.lambd, 0, 0, u, preds);
@@ -2921,7 +3025,7 @@ int tclip_hard_kmeans_run(const tclip_problem* pp, const float* x_q, float* u, f
         launch_mstats(st, (const float*)u, (const float*)x_q, (const float*)cs, (const uint8_t*)live, (const float*)nullptr, (const float*)nullptr, T, Q, K, w, 0);
         hipLaunchKernelGGL(k_zero_dead_rows, dim3(ew_grid((size_t)TK * K)), dim3(256), 0, st, (const uint8_t*)live, TK, K, w);
         // u_update + hard assignment: softmax of the squared distances, first minimum    (:128-136, :193-195)
-        dispatch_E<LaunchKmeansLogitsRows>(K, T, st, (const float*)w, x_q, (const uint8_t*)ones, Q, K, 1.0f, 1.0f, logit0);
+        launch_kmeans_logits(T, st, (const float*)w, x_q, (const uint8_t*)ones, Q, K, 1.0f, 1.0f, logit0);
         hipLaunchKernelGGL(k_softmax, dim3((T * Q * 16 + 255) / 256), dim3(256), 0, st, (const float*)logit0,
                            (const float*)nullptr, T * Q, Q, K, 0.0f, 0, 1, logit0, preds);
         // criterion mean_n ||u_old - u||_F, u <- one-hot                                       (:197-199)
@@ -2982,7 +3086,7 @@ int tclip_paddle_run(const tclip_problem* pp, const float* x_q, const float* x_s
     TCLIP_HIP(hipMemsetAsync(live, 1, (size_t)TK, st));
     for (int it = 0; it < p.iters; it++) {
         // u_update (:105-116): softmax_k(-1/2 ||w_k - z_q||^2 + lambd v_k / Q)
-        dispatch_E<LaunchKmeansLogitsRows>(K, T, st, (const float*)w, x_q, (const uint8_t*)live, Q, K, -0.5f, 1.0f, logit0);
+        launch_kmeans_logits(T, st, (const float*)w, x_q, (const uint8_t*)live, Q, K, -0.5f, 1.0f, logit0);
         hipLaunchKernelGGL(k_softmax, dim3((T * Q * 16 + 255) / 256), dim3(256), 0, st, (const float*)logit0, (const float*)v,
                            T * Q, Q, K, lambd, 0, 0, u, preds);
         // v_update (:118-124) and w_update (:142-158)
@@ -3068,7 +3172,7 @@ int tclip_bdcspn_run(const tclip_problem* pp, const float* x_q, const float* x_s
     normalize((const float*)zs, (const float*)zq, S, R, 1, (const float*)nullptr, (const float*)eta, aug);
     // soft assignment of the augmented set to the initial prototypes (:133-134)
     TCLIP_HIP(hipMemsetAsync(live, 1, (size_t)TK, st));
-    dispatch_E<LaunchKmeansLogitsRows>(K, T, st, (const float*)wn, (const float*)aug, (const uint8_t*)live, R, K, -0.5f, temp, logit);
+    launch_kmeans_logits(T, st, (const float*)wn, (const float*)aug, (const uint8_t*)live, R, K, -0.5f, temp, logit);
     hipLaunchKernelGGL(k_softmax, dim3((T * R * 16 + 255) / 256), dim3(256), 0, st, (const float*)logit, (const float*)nullptr,
                        T * R, R, K, 0.0f, 0, 0, logit, dummy);
     // rectified prototypes = assignment-weighted means of the normalised augmented set (:137-141)
@@ -3079,7 +3183,7 @@ int tclip_bdcspn_run(const tclip_problem* pp, const float* x_q, const float* x_s
     // prediction (:190-193): softmax(temp * get_logits(prototypes, query)), argmax
     normalize((const float*)prototypes, (const float*)prototypes, K, K, 1, (const float*)nullptr, (const float*)nullptr, wn);
     normalize((const float*)zq, (const float*)zq, Q, Q, 1, (const float*)nullptr, (const float*)nullptr, zqn);
-    dispatch_E<LaunchKmeansLogitsRows>(K, T, st, (const float*)wn, (const float*)zqn, (const uint8_t*)live, Q, K, -0.5f, temp, logit);
+    launch_kmeans_logits(T, st, (const float*)wn, (const float*)zqn, (const uint8_t*)live, Q, K, -0.5f, temp, logit);
     hipLaunchKernelGGL(k_softmax, dim3((T * Q * 16 + 255) / 256), dim3(256), 0, st, (const float*)logit, (const float*)nullptr,
                        T * Q, Q, K, 0.0f, 0, 0, u, preds);
     TCLIP_HIP(hipGetLastError());
@@ -3142,6 +3246,11 @@ int tclip_probability_features(const float* visual, const float* text, int64_t n
 
 int tclip_debug_set_rowset_min_rows(int32_t rows) {
     g_rowset_min_rows = rows;
+    return TCLIP_OK;
+}
+
+int tclip_debug_set_kmeans_tile(int32_t mode) {
+    g_kmeans_tile = mode;
     return TCLIP_OK;
 }
 

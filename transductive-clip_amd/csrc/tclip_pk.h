@@ -221,6 +221,17 @@ __device__ __forceinline__ f2 pk_lgamma_sleef_1_23(f2 x) {
     return r;
 }
 
+// VRSQRT14PS(x) from x's bits b (positive normal) and its table entry t, see rsqrt14_f32: (0.5 | t << 7) * 2^-k with
+// x = m 4^k, m in [1, 4), and 1.0 * 2^-k for the exact powers of 4.  With E the biased exponent, k = ((E + 1) >> 1) - 64
+// whatever E's parity, so the scaling is one subtraction of bits 24..31 of b + 2^23, moved down one place, from a base that
+// carries the 64: eight integer instructions per element where the literal form (exponent, parity, (E - 127 - parity) / 2,
+// a select on mantissa | parity) took eleven.  k_selftest compares it with rsqrt14_f32 through sqrt_torch / the MM update.
+__device__ __forceinline__ float rsqrt14_from_entry(uint32_t b, uint32_t t) {
+    uint32_t yb = 0x5f000000u | (t << 7);
+    yb = (b & 0x00ffffffu) == 0x00800000u ? 0x5f800000u : yb;          // mantissa 0 and E odd (even unbiased exponent): 4^k
+    return bits_f32(yb - (((b + 0x00800000u) >> 1) & 0x7f800000u));
+}
+
 // torch.sqrt, see sqrt_torch_inrange_f32
 // both table look-ups of a pair issued together (one memory latency per pair instead of two in a row)
 __device__ __forceinline__ f2 pk_rsqrt14(f2 x) {
@@ -230,9 +241,7 @@ __device__ __forceinline__ f2 pk_rsqrt14(f2 x) {
     const uint32_t mant0 = b0 & 0x7fffffu, mant1 = b1 & 0x7fffffu;
     const uint32_t t0 = kRsqrt14Tab[((uint32_t)par0 << 15) | (mant0 >> 8)];
     const uint32_t t1 = kRsqrt14Tab[((uint32_t)par1 << 15) | (mant1 >> 8)];
-    const uint32_t y0 = (mant0 == 0u && par0 == 0) ? 0x3f800000u : (0x3f000000u | (t0 << 7));
-    const uint32_t y1 = (mant1 == 0u && par1 == 0) ? 0x3f800000u : (0x3f000000u | (t1 << 7));
-    return f2{bits_f32(y0 - ((uint32_t)((ue0 - par0) >> 1) << 23)), bits_f32(y1 - ((uint32_t)((ue1 - par1) >> 1) << 23))};
+    return f2{rsqrt14_from_entry(b0, t0), rsqrt14_from_entry(b1, t1)};
 }
 
 __device__ __forceinline__ f2 pk_sqrt_torch_inrange(f2 x) {
@@ -241,16 +250,31 @@ __device__ __forceinline__ f2 pk_sqrt_torch_inrange(f2 x) {
     return pk_fma(pk_fma(-s, s, x), pk(0.5f) * y, s);
 }
 
+// (lgamma(1) - lg1) + m with lgamma(1) = +0, the reference's `self.log_gamma_1 - torch.lgamma(alpha + 1) + digam * alpha`
+// (em_dirichlet.py:155), as ONE subtraction m - lg1: (0 - lg1) + m and m - lg1 are the same sum of the same two numbers,
+// rounded once, and differ only in the sign of a zero result (lg1 = +0 with m = -0, i.e. alpha = 0, where the curvature is
+// the constant and t is discarded; a zero t with alpha > 1e-11 becomes |2 t / alpha^2| = +0 either way).
+__device__ __forceinline__ f2 pk_t_of(f2 lg1, f2 m) { return m - lg1; }
+
+// the quotient nume / deno of the update with the reference's IEEE behaviour at deno == 0 (total cancellation in t:
+// +-inf or nan); the zero test is wave-uniform - a product that underflows only sends the wavefront through the selects
+__device__ __forceinline__ f2 pk_update_quotient(f2 nume, f2 deno) {
+    f2 q = pk_div_rn(nume, deno);
+    if (__builtin_expect(__builtin_amdgcn_ballot_w64(deno.x * deno.y == 0.0f) != 0ull, 0))
+        q = pk_sel(deno == pk(0.0f), nume * pk(__builtin_inff()), q);
+    return q;
+}
+
 // One MM update of two parameters (psi_s: digamma of the row sum of each one's row), see mm_update_algebra.
 __device__ __forceinline__ f2 pk_mm_update_algebra(f2 a, f2 y, f2 psi_s, f2 psi1, f2 lg1) {
-    const f2 t = (pk(0.0f) - lg1) + psi1 * a;
+    const f2 t = pk_t_of(lg1, psi1 * a);
     const f2 big = __builtin_elementwise_abs(pk_div_rn(pk(2.0f) * t, a * a));
     const f2 curv = pk_sel(a > pk(1e-11f), big, pk(1.6449340668482264f));
     f2 b = (psi1 - psi_s) - curv * a;
     b = b - y;
-    const f2 delta = b * b + pk(4.0f) * curv;
+    const f2 delta = pk_fma(pk(4.0f), curv, b * b);
     const f2 nume = -b + pk_sqrt_torch_inrange(delta), deno = pk(2.0f) * curv;
-    return pk_sel(deno == pk(0.0f), nume * pk(__builtin_inff()), pk_div_rn(nume, deno));
+    return pk_update_quotient(nume, deno);
 }
 
 // lg1 = lgamma(a+1): the caller supplies the large-argument results (a+1 >= 2.3) it evaluated
@@ -271,13 +295,13 @@ struct PkUpdateStage {
 };
 // stage 1 from psi1 = digamma(a+1) and lg1 = lgamma(a+1)
 __device__ __forceinline__ PkUpdateStage pk_mm_update_stage1_given(f2 a, f2 y, f2 psi_s, f2 psi1, f2 lg1) {
-    const f2 t = (pk(0.0f) - lg1) + psi1 * a;
+    const f2 t = pk_t_of(lg1, psi1 * a);
     const f2 bigv = __builtin_elementwise_abs(pk_div_rn(pk(2.0f) * t, a * a));
     PkUpdateStage st;
     st.curv = pk_sel(a > pk(1e-11f), bigv, pk(1.6449340668482264f));
     f2 b = (psi1 - psi_s) - st.curv * a;
     st.b = b - y;
-    st.delta = st.b * st.b + pk(4.0f) * st.curv;
+    st.delta = pk_fma(pk(4.0f), st.curv, st.b * st.b);           // 4 curv is exact: one rounding, as b b + 4 curv has
     const uint32_t b0 = f32_bits(st.delta.x), b1 = f32_bits(st.delta.y);
     st.t0 = kRsqrt14Tab[((((b0 >> 23) - 127u) & 1u) << 15) | ((b0 & 0x7fffffu) >> 8)];
     st.t1 = kRsqrt14Tab[((((b1 >> 23) - 127u) & 1u) << 15) | ((b1 & 0x7fffffu) >> 8)];
@@ -289,30 +313,24 @@ __device__ __forceinline__ PkUpdateStage pk_mm_update_stage1(f2 a, f2 y, f2 psi_
     const f2 lg_small = pk_lgamma_sleef_1_23(pk_sel(big, pk(2.0f), x1));
     const f2 psi1 = pk_digamma_xp1(a, tab);
     const f2 lg1 = pk_sel(big, lg_big, lg_small);
-    const f2 t = (pk(0.0f) - lg1) + psi1 * a;
+    const f2 t = pk_t_of(lg1, psi1 * a);
     const f2 bigv = __builtin_elementwise_abs(pk_div_rn(pk(2.0f) * t, a * a));
     PkUpdateStage st;
     st.curv = pk_sel(a > pk(1e-11f), bigv, pk(1.6449340668482264f));
     f2 b = (psi1 - psi_s) - st.curv * a;
     st.b = b - y;
-    st.delta = st.b * st.b + pk(4.0f) * st.curv;
+    st.delta = pk_fma(pk(4.0f), st.curv, st.b * st.b);           // 4 curv is exact: one rounding, as b b + 4 curv has
     const uint32_t b0 = f32_bits(st.delta.x), b1 = f32_bits(st.delta.y);
     st.t0 = kRsqrt14Tab[((((b0 >> 23) - 127u) & 1u) << 15) | ((b0 & 0x7fffffu) >> 8)];
     st.t1 = kRsqrt14Tab[((((b1 >> 23) - 127u) & 1u) << 15) | ((b1 & 0x7fffffu) >> 8)];
     return st;
 }
 __device__ __forceinline__ f2 pk_mm_update_stage2(const PkUpdateStage& st) {
-    const uint32_t b0 = f32_bits(st.delta.x), b1 = f32_bits(st.delta.y);
-    const int ue0 = (int)(b0 >> 23) - 127, ue1 = (int)(b1 >> 23) - 127;
-    const int par0 = ue0 & 1, par1 = ue1 & 1;
-    const uint32_t mant0 = b0 & 0x7fffffu, mant1 = b1 & 0x7fffffu;
-    const uint32_t y0 = (mant0 == 0u && par0 == 0) ? 0x3f800000u : (0x3f000000u | (st.t0 << 7));
-    const uint32_t y1 = (mant1 == 0u && par1 == 0) ? 0x3f800000u : (0x3f000000u | (st.t1 << 7));
-    const f2 yr{bits_f32(y0 - ((uint32_t)((ue0 - par0) >> 1) << 23)), bits_f32(y1 - ((uint32_t)((ue1 - par1) >> 1) << 23))};
+    const f2 yr{rsqrt14_from_entry(f32_bits(st.delta.x), st.t0), rsqrt14_from_entry(f32_bits(st.delta.y), st.t1)};
     const f2 s = st.delta * yr;
     const f2 root = pk_fma(pk_fma(-s, s, st.delta), pk(0.5f) * yr, s);
     const f2 nume = -st.b + root, deno = pk(2.0f) * st.curv;
-    return pk_sel(deno == pk(0.0f), nume * pk(__builtin_inff()), pk_div_rn(nume, deno));
+    return pk_update_quotient(nume, deno);
 }
 
 }  // namespace tclip

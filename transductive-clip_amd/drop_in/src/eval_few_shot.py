@@ -133,11 +133,15 @@ class Evaluator_few_shot:
 
     def sample_indices(self, all_labels_support, all_labels_query):
         a = self.args
-        q_all, s_all = [], []
+        q_all, s_all, lists = [], [], None
         for _ in range(int(a.number_tasks / a.batch_size)):
             sampler = CategoriesSampler_few_shot(a.batch_size, a.k_eff, a.n_class, a.shots, a.n_query,
                                                  force_query_size=True)
-            sampler.create_list_classes(all_labels_support, all_labels_query)
+            if lists is None:             # label -> index lists: no random numbers involved, built once (see eval_zero_shot.py)
+                sampler.create_list_classes(all_labels_support, all_labels_query)
+                lists = (sampler.m_ind_support, sampler.m_ind_query)
+            else:
+                sampler.m_ind_support, sampler.m_ind_query = lists
             q_all.append(torch.stack(list(SamplerQuery_few_shot(sampler)), 0))
             s_all.append(torch.stack(list(SamplerSupport_few_shot(sampler)), 0))
         return torch.stack(s_all, 0), torch.stack(q_all, 0)
@@ -181,7 +185,8 @@ class Evaluator_few_shot:
             si, qi = s_idx[ids].reshape(-1), q_idx[ids].reshape(-1)
             # The EM-Dirichlet classes read the task rows from the tables through the index tensors (label flip and column
             # permutation inside the kernels): x_s (T,S,K) - 1.6 GB per 100 tasks at K = 1000, 4 shots - is never built
-            if hasattr(m, "run_tables") and a.use_softmax_feature and not getattr(a, 'materialise_tasks', False):
+            if a.name_method in ('EM_DIRICHLET', 'HARD_EM_DIRICHLET') and a.use_softmax_feature \
+                    and not getattr(a, 'materialise_tasks', False):
                 rel = relabel_indices(lab_s[si].view(-1, S), lab_q[qi].view(-1, Q), K)
                 if rel is not None:
                     cols, y_s, y_q = rel

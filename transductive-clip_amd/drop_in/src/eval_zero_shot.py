@@ -79,10 +79,16 @@ class Evaluator_zero_shot:
         """(n_batches, batch_size, n_query) int64 index tensor, drawn batch by batch exactly as
         the reference does (a fresh sampler per batch)."""
         a = self.args
-        out = []
+        out, lists = [], None
         for _ in range(int(a.number_tasks / a.batch_size)):
             sampler = CategoriesSampler_zero_shot(a.batch_size, a.k_eff, a.n_class, a.n_query, force_query_size=True)
-            sampler.create_list_classes(all_labels_query)
+            # the label -> index lists are a function of the labels alone and consume no random numbers: built for the
+            # first batch, shared by the others (the reference rebuilds them per batch, sampler_zero_shot.py:31-36)
+            if lists is None:
+                sampler.create_list_classes(all_labels_query)
+                lists = sampler.m_ind_query
+            else:
+                sampler.m_ind_query = lists
             out.append(torch.stack(list(SamplerQuery_zero_shot(sampler)), 0))
         return torch.stack(out, 0)
 

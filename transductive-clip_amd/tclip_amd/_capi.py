@@ -33,6 +33,7 @@ _SIGNATURES = {
     "tclip_cluster_prototypes": (ctypes.c_int, [ctypes.c_int32] * 3 + [_P] * 6 + [ctypes.c_size_t, _P]),
     "tclip_match_clusters_host": (ctypes.c_int, [ctypes.c_int32] * 3 + [_P] * 5 + [ctypes.c_int32, _P, _P]),
     "tclip_match_clusters_host_strided": (ctypes.c_int, [ctypes.c_int32] * 3 + [_P] * 5 + [ctypes.c_int32, ctypes.c_int32, _P, _P]),
+    "tclip_host_threads": (ctypes.c_int, []),
     "tclip_gather_rows": (ctypes.c_int, [_P, ctypes.c_int64, ctypes.c_int32, _P, ctypes.c_int64, _P, _P]),
     "tclip_soft_kmeans_workspace_bytes": (ctypes.c_size_t, [ctypes.POINTER(Problem)]),
     "tclip_soft_kmeans_run": (ctypes.c_int, [ctypes.POINTER(Problem), _P, ctypes.c_float, _P, _P, _P, _P, ctypes.c_size_t, _P]),
@@ -57,6 +58,7 @@ _SIGNATURES = {
     "tclip_debug_set_probe_chunks": (ctypes.c_int, [ctypes.c_int32]),
     "tclip_debug_set_rowset_min_rows": (ctypes.c_int, [ctypes.c_int32]),
     "tclip_debug_set_mm_split": (ctypes.c_int, [ctypes.c_int32]),
+    "tclip_debug_set_kmeans_tile": (ctypes.c_int, [ctypes.c_int32]),
     "tclip_profile_collect": (ctypes.c_int, [ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_double),
                                              ctypes.POINTER(ctypes.c_int64), ctypes.POINTER(ctypes.c_int64)]),
 }
@@ -89,6 +91,20 @@ def lib():
             raise RuntimeError("libtclip.so ABI version mismatch")
         _lib = l
     return _lib
+
+
+def source_digest():
+    """sha1 over the kernel sources (csrc/*.hip, *.h, *.inc, *.cpp, in name order): what a committed profile was taken on.
+    profiles/pmc_current.json stores it and bench.py reports the PMC-derived fields only while it matches the tree."""
+    import hashlib
+    csrc = os.path.join(os.path.dirname(_HERE), "csrc")
+    h = hashlib.sha1()
+    for name in sorted(os.listdir(csrc)):
+        if name.endswith((".hip", ".h", ".inc", ".cpp")):
+            h.update(name.encode())
+            with open(os.path.join(csrc, name), "rb") as f:
+                h.update(f.read())
+    return h.hexdigest()
 
 
 def check(code, what):

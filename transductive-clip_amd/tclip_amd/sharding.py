@@ -113,3 +113,25 @@ def gather_batch_results(local, n_batches, rank=None, world_size=None):
         if ids:
             out[ids] = blocks[r][: len(ids)]
     return out
+
+
+def gather_rank_values(value, device=None):
+    """One float per rank, on every rank (bench.py: the ranks' step times, whose maximum is the job's time and whose
+    spread is the skew).  `device`: where the exchanged tensor lives (the rank's GPU under nccl, None = CPU under gloo)."""
+    rank, world_size = world()
+    if world_size == 1:
+        return [float(value)]
+    mine = torch.tensor([float(value)], dtype=torch.float64, device=device if device is not None else "cpu")
+    every = [torch.zeros_like(mine) for _ in range(world_size)]
+    dist.all_gather(every, mine)
+    return [float(t.item()) for t in every]
+
+
+def check_one_device_per_rank(device_index, device=None):
+    """Every rank of a one-node job must drive its own GPU: gathers the ranks' device indices and raises when two ranks
+    share one (a launcher that did not export LOCAL_RANK, or a script that ignored it, would run N ranks on cuda:0 and
+    report N times the single-GPU rate as if it scaled).  Returns the list of indices."""
+    seen = [int(v) for v in gather_rank_values(float(device_index), device)]
+    if len(set(seen)) != len(seen):
+        raise RuntimeError(f"ranks share a GPU: device index per rank = {seen}")
+    return seen
