@@ -1,0 +1,27 @@
+#!/usr/bin/env python3
+"""SOFT_KMEANS engine time with the 32-lanes-per-class distance kernel (tclip_debug_set_kmeans_tile 0) and with the default rule
+(one lane per class on LDS tiles for rows of 32 .. 511 elements): python scripts/gpu_kmeans_ab.py [K T iters]..."""
+import os, sys, time
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "transductive-clip_amd"))
+import torch
+from tclip_amd import _capi, engine, synth
+shapes = [(397, 1000, 20), (100, 1000, 20), (47, 1000, 20), (256, 500, 20)]
+if len(sys.argv) > 1:
+    a = [int(v) for v in sys.argv[1:]]
+    shapes = [tuple(a[i:i + 3]) for i in range(0, len(a), 3)]
+for K, T, iters in shapes:
+    x, _ = synth.make_query_tasks(T, K, seed=6); x = x.cuda()
+    line, ref = [], None
+    for mode in (0, -1):
+        _capi.lib().tclip_debug_set_kmeans_tile(mode)
+        best = 1e9
+        for rep in range(3):
+            torch.cuda.synchronize(); t = time.time()
+            res = engine.run_soft_kmeans(x, iters=iters, temperature=30)
+            torch.cuda.synchronize(); best = min(best, time.time() - t)
+        same = ref is None or all(torch.equal(a, b) for a, b in zip(res, ref))
+        ref = ref or res
+        line.append(f"mode {mode}: {best * 1e3:.1f} ms same={same}")
+    _capi.lib().tclip_debug_set_kmeans_tile(-1)
+    print(f"SOFT_KMEANS K={K} T={T} iters={iters}  " + "  ".join(line), flush=True)

@@ -187,6 +187,8 @@ def test_relabel_indices_equals_get_task_relabelling():
     y_missing = y_s.clone()
     y_missing[2][y_missing[2] == 3] = 4
     assert relabel_indices(y_missing, y_q, K) is None
+    # a support set with MORE label values than n_class columns' worth takes the per-task path and is reported too
+    assert relabel_indices(y_s, y_q, K + 1) is None
 
 
 def _worker_eight(rank, world, port, out):

@@ -1538,10 +1538,13 @@ __global__ __launch_bounds__(256) void k_kmeans_logits_rows(const float* __restr
 // Rows of 32 .. 511 elements (fewer than 16 steps: torch's cascade never dumps; 64 x 511 floats of LDS = 131 KB).
 constexpr int kKmeansTile = 64;
 #ifndef TCLIP_KMEANS_TILE_THREADS
-#define TCLIP_KMEANS_TILE_THREADS 512     // the tile's LDS (101 KB at K = 397) allows one block per CU: eight wavefronts share it, two per SIMD
+#define TCLIP_KMEANS_TILE_THREADS 1024    // the tile's LDS (101 KB at K = 397) allows one block per CU: sixteen wavefronts share it, four per SIMD (512: 74 against 66 ms per 1000-task SOFT_KMEANS call)
 #endif
 constexpr int kKmeansTileThreads = TCLIP_KMEANS_TILE_THREADS;
-__global__ __launch_bounds__(512) void k_kmeans_logits_tile(const float* __restrict__ w, const float* __restrict__ z,
+#ifndef TCLIP_KMEANS_PREFETCH
+#define TCLIP_KMEANS_PREFETCH 1        // 1000 tasks, K = 397, 20 iterations of SOFT_KMEANS: 66.5 ms against 73.7 without
+#endif
+__global__ __launch_bounds__(TCLIP_KMEANS_TILE_THREADS) void k_kmeans_logits_tile(const float* __restrict__ w, const float* __restrict__ z,
                                                             const uint8_t* __restrict__ need, int Q, int K, int stride, float pre,
                                                             float temperature, float* __restrict__ logit0) {
     extern __shared__ float wt[];                                   // [kKmeansTile][stride]
@@ -1553,9 +1556,20 @@ __global__ __launch_bounds__(512) void k_kmeans_logits_tile(const float* __restr
     if (!__syncthreads_or(ok)) return;                              // no class of the tile moved
     const int rows = K - k0 < kKmeansTile ? K - k0 : kKmeansTile;
     const float* wsrc = w + ((size_t)t * K + k0) * K;
-    for (int i = threadIdx.x; i < rows * K; i += blockDim.x) {
-        const int r = i / K;
-        wt[r * stride + (i - r * K)] = wsrc[i];
+    {   // eight loads in flight per thread (a loop of load - wait - store took as long as the tile's arithmetic: a block
+        // is alone on its CU, nothing else hides the latency); word i of the tile goes to row i / K, the quotient by steps
+        const int n = rows * K, step = blockDim.x;
+        const int pad = stride - K;                                 // 0 or 1 words per row
+        for (int i0 = threadIdx.x; i0 < n; i0 += 8 * step) {
+            float v[8];
+#pragma unroll
+            for (int j = 0; j < 8; j++) v[j] = i0 + j * step < n ? wsrc[i0 + j * step] : 0.0f;
+#pragma unroll
+            for (int j = 0; j < 8; j++) {
+                const int i = i0 + j * step;
+                if (i < n) wt[i + (pad ? i / K : 0)] = v[j];
+            }
+        }
     }
     __syncthreads();
     const float* wl = wt + (lane < rows ? lane : rows - 1) * stride;     // lanes beyond the last class recompute it; nothing is stored
@@ -1565,6 +1579,26 @@ __global__ __launch_bounds__(512) void k_kmeans_logits_tile(const float* __restr
         float acc[32];
 #pragma unroll
         for (int sl = 0; sl < 32; sl++) acc[sl] = 0.0f;
+#if TCLIP_KMEANS_PREFETCH
+        // the query row's next 32 values are requested (scalar loads, ~300 cycles from L2) before the current step's
+        // arithmetic, not at their first use: with one block per CU there are too few wavefronts to hide that latency
+        float zc[32];
+#pragma unroll
+        for (int sl = 0; sl < 32; sl++) zc[sl] = zq[sl];
+        for (int m = 0; m < size_ilp; m++) {
+            float zn[32];
+            const int nx = m + 1 < size_ilp ? 32 * (m + 1) : 32 * m;   // the last step re-reads its own values (never used)
+#pragma unroll
+            for (int sl = 0; sl < 32; sl++) zn[sl] = zq[nx + sl];
+#pragma unroll
+            for (int sl = 0; sl < 32; sl++) {
+                const float df = wl[32 * m + sl] - zc[sl];
+                acc[sl] += df * df;
+            }
+#pragma unroll
+            for (int sl = 0; sl < 32; sl++) zc[sl] = zn[sl];
+        }
+#else
         for (int m = 0; m < size_ilp; m++) {
 #pragma unroll
             for (int sl = 0; sl < 32; sl++) {
@@ -1572,6 +1606,7 @@ __global__ __launch_bounds__(512) void k_kmeans_logits_tile(const float* __restr
                 acc[sl] += df * df;
             }
         }
+#endif
         int d = 32 * size_ilp;
         for (int i = 0; i < nleft; i++, d += 8) {                   // whole vectors beyond the 4-way part join accumulator 0
 #pragma unroll
@@ -2522,12 +2557,119 @@ static void launch_kmeans_logits(int T, hipStream_t st, const float* w, const fl
 
 // M-step statistics / centroids / prototypes: rows whose K columns all lie in torch's cascade region
 // go through the 8-rows-per-thread kernel, the last few rows through the one-row kernel.
+// The same statistics with the task's feature columns staged ONCE per block (round 4), for the reference's 75 queries: a block
+// owns 64 columns d of one task - f[t, 0..74, d0..d0+63] in 19 KB of LDS - and a range of classes; each of its four
+// wavefronts walks its share of the classes in chunks of eight, lane = column; u[t, q, k .. k+7] is wave-uniform and arrives
+// as one scalar load per (q, chunk).  k_mstats_rows reads the task's feature block once per eight classes from L2 (K = 397:
+// 49 times, 6.6 GB per call, which is what bounded it: 1.65 ms for 1 000 tasks); here it is read once per `rows_per_block`
+// classes and the kernel is left with its 2 x 75 VALU instructions per output.
+// Same operations in the same order: products u f added in query order, a0 dumped into a1 after every 16 queries
+// (dsum_cascade with n = 75: four dumps, eleven leftovers), a0 + a1 + a2 + a3 with a2 = a3 = +0 (the zero additions
+// decide the sign of a zero sum).  Rows of the cascade region only, as k_mstats_rows.
+constexpr int kColsQ = 75, kColsChunk = 8, kColsWaves = 4;
+__global__ __launch_bounds__(64 * kColsWaves) void k_mstats_cols75(const float* __restrict__ u, const float* __restrict__ f,
+                                                                   const float* __restrict__ cs, const uint8_t* __restrict__ live,
+                                                                   const float* __restrict__ sup, const float* __restrict__ cnt, int K,
+                                                                   int k_rows, int rows_per_block, float* __restrict__ y, int paddle) {
+    __shared__ float zt[kColsQ * 64];
+    const int t = blockIdx.z, d0 = blockIdx.x * 64;
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int kb = blockIdx.y * rows_per_block;
+    const int ke = kb + rows_per_block < k_rows ? kb + rows_per_block : k_rows;
+    if (kb >= ke) return;
+    {   // nothing to do for a block without a live class (block-uniform)
+        bool any = false;
+        for (int k = kb; k < ke; k++) any = any || live[(size_t)t * K + k];
+        if (!any) return;
+    }
+    const float* ft = f + (size_t)t * kColsQ * K;
+    for (int i = threadIdx.x; i < kColsQ * 64; i += 64 * kColsWaves) {
+        const int q = i >> 6, dc = d0 + (i & 63);
+        zt[i] = ft[(size_t)q * K + (dc < K ? dc : K - 1)];
+    }
+    __syncthreads();
+    const int d = d0 + lane;
+    const float* ut = u + (size_t)t * kColsQ * K;
+    const float* zl = zt + lane;
+    for (int kc = kb + wave * kColsChunk; kc < ke; kc += kColsWaves * kColsChunk) {
+        const int k0 = kc + kColsChunk <= k_rows ? kc : k_rows - kColsChunk;   // the last chunk overlaps its predecessor (same values again)
+        bool any = false;
+#pragma unroll
+        for (int j = 0; j < kColsChunk; j++) any = any || live[(size_t)t * K + k0 + j];
+        if (!any) continue;
+        float a0[kColsChunk], a1[kColsChunk];
+#pragma unroll
+        for (int j = 0; j < kColsChunk; j++) a0[j] = a1[j] = 0.0f;
+        const float* uk = ut + k0;                                  // indexed, not walked: a pointer that moves through the loop
+                                                                    // turned these wave-uniform loads into per-lane ones
+#pragma unroll 1
+        for (int g = 0; g < kColsQ / 8; g++) {                      // nine groups of eight queries; a dump after every second group
+#pragma unroll
+            for (int i = 0; i < 8; i++) {
+                const int q = 8 * g + i;
+                const float zq = zl[q * 64];
+#pragma unroll
+                for (int j = 0; j < kColsChunk; j++) a0[j] += uk[(size_t)q * K + j] * zq;
+            }
+            if (g & 1) {
+#pragma unroll
+                for (int j = 0; j < kColsChunk; j++) { a1[j] += a0[j]; a0[j] = 0.0f; }
+            }
+        }
+#pragma unroll
+        for (int q = 8 * (kColsQ / 8); q < kColsQ; q++) {          // the last three
+            const float zq = zl[q * 64];
+#pragma unroll
+            for (int j = 0; j < kColsChunk; j++) a0[j] += uk[(size_t)q * K + j] * zq;
+        }
+        if (d >= K) continue;
+#pragma unroll
+        for (int j = 0; j < kColsChunk; j++) {
+            const size_t row = (size_t)t * K + k0 + j;
+            if (!live[row]) continue;
+            float s = a0[j];
+            s += a1[j];
+            s += 0.0f;                                  // a2, a3 of the cascade: never filled with 75 terms, but added
+            s += 0.0f;
+            const float c = cs[row];
+            if (paddle == 2) {
+                y[row * K + d] = s / c;
+            } else if (sup && paddle) {
+                y[row * K + d] = (s + sup[row * K + d]) / (c + cnt[row]);
+            } else if (sup) {
+                const float w = 1.0f / (cnt[row] + c);
+                y[row * K + d] = w * (sup[row * K + d] + s);
+            } else {
+                y[row * K + d] = s / (c < kEpsF ? kEpsF : c);
+            }
+        }
+    }
+}
+
+static int g_mstats_cols = -1;          // tclip_debug_set_kmeans_tile also switches this kernel (0: k_mstats_rows for every shape)
 template <bool kCov>
 static void launch_mstats_mode(hipStream_t st, const float* u, const float* f, const float* cs, const uint8_t* live,
                                const float* sup, const float* cnt, int T, int Q, int K, float* y, int paddle, const float* wc) {
     const long ncols = (long)K * K;
     const int full_rows = ncols >= 8 ? (int)(((ncols / 32) * 32) / K) : 0;      // rows 0 .. full_rows-1 are all-cascade
-    const int groups = full_rows / kMstatsRows;
+    int groups = full_rows / kMstatsRows;
+    if (!kCov && Q == kColsQ && full_rows >= kColsChunk && g_mstats_cols != 0) {
+        // the column kernel takes every row of the cascade region; enough blocks to fill the machine, at least 32 rows each
+        const int dtiles = (K + 63) / 64;
+        int splits = (int)((8192 + (long)T * dtiles - 1) / ((long)T * dtiles));
+        if (splits > full_rows / (kColsWaves * kColsChunk)) splits = full_rows / (kColsWaves * kColsChunk);
+        if (splits < 1) splits = 1;
+        int rows_per_block = ((full_rows + splits - 1) / splits + kColsChunk - 1) / kColsChunk * kColsChunk;
+        splits = (full_rows + rows_per_block - 1) / rows_per_block;
+        hipLaunchKernelGGL(k_mstats_cols75, dim3(dtiles, splits, T), dim3(64 * kColsWaves), 0, st, u, f, cs, live, sup, cnt, K, full_rows,
+                           rows_per_block, y, paddle);
+        groups = full_rows / kMstatsRows;
+        const int k_first = full_rows;
+        if (k_first < K)
+            hipLaunchKernelGGL(k_mstats<kCov>, dim3((K + 63) / 64, K - k_first, T), dim3(64), 0, st, u, f, cs, live, sup, cnt, Q, K, y,
+                               paddle, k_first, wc);
+        return;
+    }
     if (groups > 0)
         hipLaunchKernelGGL(k_mstats_rows<kCov>, dim3((K + 63) / 64, groups, T), dim3(64), 0, st, u, f, cs, live, sup, cnt, Q, K, y,
                            paddle, wc);
@@ -3251,6 +3393,7 @@ int tclip_debug_set_rowset_min_rows(int32_t rows) {
 
 int tclip_debug_set_kmeans_tile(int32_t mode) {
     g_kmeans_tile = mode;
+    g_mstats_cols = mode;
     return TCLIP_OK;
 }
 

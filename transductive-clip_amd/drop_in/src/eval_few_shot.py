@@ -38,6 +38,14 @@ def relabel_indices(y_s, y_q, n_class):
     features: per task the column permutation `unique_labels` as an int32 row and the re-indexed support / query labels.
     None when some task's support set misses a class (the permuted task would have fewer than n_class columns; the caller
     materialises the tensors then, as the reference does)."""
+    y_s, y_q = y_s.long(), y_q.long()
+    if y_s.numel() and int(y_s.min()) >= 0 and int(y_s.max()) < n_class:
+        present = torch.zeros(y_s.shape[0], n_class, dtype=torch.bool).scatter_(1, y_s, True)
+        if bool(present.all()):
+            # every class in every support set (what the reference's sampler draws): unique_labels = flip(arange(K)) for
+            # every task, i.e. column d <- table column K-1-d and label y <- K-1-y, without a torch.unique per task
+            cols = torch.arange(n_class - 1, -1, -1, dtype=torch.int32).repeat(y_s.shape[0], 1)
+            return cols, n_class - 1 - y_s, n_class - 1 - y_q
     cols, ys2, yq2 = [], [], []
     for t in range(y_s.shape[0]):
         uniq, lut = label_permutation(y_s[t])
