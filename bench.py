@@ -19,7 +19,7 @@ host assignment), and for N>1 the single RCCL all_gather of the per-task accurac
 
 Extra objects on the JSON line:
   roofline     the dominant kernels - k_mm_live (first outer iteration) and k_mm_split (the later ones), the MM loop of
-               the live rows - timed live with HIP events around each of their launches on the streams they run on
+               the live rows (`per_kernel`: each of the two alone) - timed live with HIP events around each of their launches on the streams they run on
                (independent batches use a few internal streams, so launches overlap: `achieved` divides by the time
                during which at least one launch was running, `avg_launch_ms` is the plain mean launch duration).
                The path is fp32 vector-ALU bound, so the bound is "valu": achieved = 48
@@ -179,8 +179,9 @@ def load_pmc():
 
 
 def roofline_of(prof, steps, K, pmc_key):
-    """prof = engine.profile_collect() of `steps` timed steps."""
-    mm_ms, mm_launch_sum, mm_launches, updates = prof
+    """prof = engine.profile_collect() of `steps` timed steps (+ engine.profile_last_kernels() as a fifth entry)."""
+    mm_ms, mm_launch_sum, mm_launches, updates = prof[:4]
+    kernels = prof[4] if len(prof) > 4 else {}
     achieved = FLOP_EQ_PER_UPDATE * updates / (mm_ms * 1e-3) / 1e12 if mm_ms > 0 else 0.0
     # algorithmic HBM bytes of the MM launches: every listed row is read (alpha, y) and written (alpha)
     # once per launch = 12 bytes per element per <=51-iteration launch
@@ -198,6 +199,16 @@ def roofline_of(prof, steps, K, pmc_key):
            "algorithmic_bytes_per_launch": rows_bytes / max(mm_launches, 1),
            "hbm": {"bound": "hbm", "achieved": hbm_gbs, "peak": PEAK_HBM_GBS, "unit": "GB/s",
                    "frac": hbm_gbs / PEAK_HBM_GBS, "algorithmic_bytes_per_step": rows_bytes / steps}}
+    # the two kernels of the combined figure, each against the same peak: busy = union of ITS launches' intervals (launches of
+    # different stream groups overlap, so the two busy times add up to more than the combined one)
+    out["per_kernel"] = {}
+    for name, (busy, lsum, n, upd) in kernels.items():
+        if n:
+            tf = FLOP_EQ_PER_UPDATE * upd / (busy * 1e-3) / 1e12 if busy > 0 else 0.0
+            out["per_kernel"][name] = {"achieved": tf, "frac": tf / PEAK_VALU_TFLOPS, "kernel_busy_ms_per_step": busy / steps,
+                                       "launches_per_step": n / steps, "avg_launch_ms": lsum / n,
+                                       "element_updates_per_step": upd / steps,
+                                       "element_updates_per_s": upd / (busy * 1e-3) if busy > 0 else 0.0}
     pmc = load_pmc()
     if pmc and pmc_key in pmc and pmc[pmc_key].get("csrc_sha1") != _capi.source_digest():
         # the committed counters were taken on other kernel sources: traffic, clock and the fractions derived from them
@@ -298,7 +309,7 @@ def main():
             res = step()
         fence()
         elapsed = time.perf_counter() - t0
-        prof = engine.profile_collect()
+        prof = engine.profile_collect() + (engine.profile_last_kernels(),)
         engine.profile_enable(False)
         per_rank = sharding.gather_rank_values(elapsed, dev if args.backend == "nccl" else None) if dist_on else [elapsed]
         elapsed = max(per_rank)                          # the job is done when its slowest rank is

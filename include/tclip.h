@@ -272,6 +272,9 @@ int tclip_probability_features(const float* visual, const float* text, int64_t n
 int tclip_profile_enable(int on);
 int tclip_profile_collect(double* mm_busy_ms, double* mm_launch_ms_sum, int64_t* mm_launches,
                           int64_t* element_updates);
+/* The same four figures of the LAST tclip_profile_collect of this thread per kernel: index 0 = k_mm_live (the first outer
+ * iteration and row lengths without a split instantiation), 1 = k_mm_split.  Every argument points to two values. */
+int tclip_profile_last_kernels(double* busy_ms, double* launch_ms_sum, int64_t* launches, int64_t* element_updates);
 
 /* Dead rows are spared the rest of their schedule once a limit-cycle probe (run after each of the
  * first `chunks` 50-iteration chunks) finds them on a cycle of the fp32 map - an exact shortcut.

@@ -973,6 +973,9 @@ __global__ __launch_bounds__(64 * W, (E > 16 ? TCLIP_MM_WAVES_LARGE : TCLIP_MM_W
 #ifndef TCLIP_SPLIT_WAVES_MID
 #define TCLIP_SPLIT_WAVES_MID 4    // wavefronts per SIMD requested for 9..16 registers per lane
 #endif
+#ifndef TCLIP_SPLIT_OPAQUE_PLANE1
+#define TCLIP_SPLIT_OPAQUE_PLANE1 0
+#endif
 #ifndef TCLIP_SPLIT_MIN_E
 #define TCLIP_SPLIT_MIN_E 5        // shorter rows fill too little of a dense pass: measured with 16 lanes per row on 1000 tasks,
                                    // split against k_mm_live: K = 10 +42 %, 37 +6 %, 47 +7 %, 64 +1 %, 80 -4.5 %, 96 -5 %, 100 -11 %,
@@ -1217,7 +1220,17 @@ __device__ __forceinline__ void mm_iterate_wave_split(float (&beta)[E], const Ro
     }
     // phase C
     wave_lds_handoff();
+#if TCLIP_SPLIT_OPAQUE_PLANE1
+    {   // plane 1 through a pointer the compiler cannot relate to plane 0: it then fetches the two lgamma words of a register
+        // pair into one register pair and the two digamma words into another (four ds_read_b32) instead of merging the
+        // (lgamma, digamma) words of each element into a ds_read2st64 and transposing them with three v_mov per pair
+        const float* p1 = my1;
+        asm volatile("" : "+v"(p1));
+        split_apply_updates<E, G>(beta, yv, K, lane, psi_s, my0, p1, slot, measure, num, den);
+    }
+#else
     split_apply_updates<E, G>(beta, yv, K, lane, psi_s, my0, my1, slot, measure, num, den);
+#endif
     wave_lds_handoff();
 }
 
@@ -2335,9 +2348,14 @@ static size_t align_up(size_t x) { return (x + 255) & ~(size_t)255; }
 struct Profile {
     bool on = false;
     std::vector<hipEvent_t> ev;      // start/stop pairs, reused across collections
+    std::vector<uint8_t> kind;       // per pair: 0 = k_mm_live, 1 = k_mm_split
     size_t used = 0;
-    unsigned long long* counter = nullptr;
+    unsigned long long* counter = nullptr;      // [2]: element-updates executed by k_mm_live / k_mm_split
+    // per-kernel figures of the last collection (tclip_profile_last_kernels)
+    double last_busy[2] = {0, 0}, last_sum[2] = {0, 0};
+    int64_t last_launches[2] = {0, 0}, last_updates[2] = {0, 0};
 };
+static thread_local bool g_last_mm_was_split = false;     // which kernel the last launch_mm(kMMSplit / kMMLive) started
 thread_local Profile g_prof;
 static int g_probe_chunks = TCLIP_PROBE_CHUNKS;     // tclip_debug_set_probe_chunks
 static int g_rowset_min_rows = -1;                  // tclip_debug_set_rowset_min_rows; negative: the default rule
@@ -2457,6 +2475,7 @@ static void launch_mm_EG(int dead, int rows, hipStream_t st, const MMArgs& a) {
             int sgrid = (rows + kSplitRows - 1) / kSplitRows;
             if (sgrid > 256 * 64) sgrid = 256 * 64;
             hipLaunchKernelGGL((k_mm_split<E, G>), dim3(sgrid), dim3(64), 0, st, a);
+            g_last_mm_was_split = true;
             return;
         }
         dead = kMMLive;
@@ -2486,6 +2505,25 @@ static void launch_mm_G(int need, int dead, int rows, hipStream_t st, const MMAr
         if (need <= 28) return launch_mm_EG<28, G>(dead, rows, st, a);
         return launch_mm_EG<32, G>(dead, rows, st, a);
     }
+}
+// registers per lane launch_mm_G<G> picks for `need`
+static int mm_regs_of(int need, int G) {
+    if ((G < 32 || need <= 8) && need <= 8) return need;
+    if (need <= 10) return 10;
+    if (need <= 13) return 13;
+    if (need <= 16) return 16;
+    if (need <= 20) return 20;
+    if (need <= 24) return 24;
+    return need <= 28 ? 28 : 32;
+}
+// does launch_mm(kMMSplit, K, ..) start k_mm_split (true) or fall back to k_mm_live (no instantiation for this row length)?
+static bool mm_has_split(int K) {
+    const bool wide = g_rowset_min_rows == 0;
+    int E;
+    if (K >= TCLIP_G64_MIN_K && K >= 512 && !wide && TCLIP_G64_MIN_K > 0) E = 16;
+    else if (K <= TCLIP_G16_MAX_K && !wide) E = mm_regs_of((K + 15) / 16, 16);
+    else E = mm_regs_of((K + 31) / 32, 32);
+    return E <= TCLIP_SPLIT_MAX_E && E >= TCLIP_SPLIT_MIN_E;
 }
 static void launch_mm(int dead, int K, int rows, hipStream_t st, const MMArgs& a) {
     const bool wide = g_rowset_min_rows == 0;              // test hook: the 32-lane layout for every row length
@@ -2796,14 +2834,21 @@ static int enqueue_batches(const tclip_problem& p, const RowSrc& q_src, const Ro
             a.l1 = 50 * (c + 1) < p.iter_mm - 1 ? 50 * (c + 1) : p.iter_mm - 1;
             a.has_check = (a.l1 > 0 && a.l1 % 50 == 0) ? 1 : 0;
             a.n_checks = n_checks > 0 ? n_checks : 1;
-            a.work_counter = g_prof.on ? g_prof.counter : nullptr;
+            // class-split kernel once the parameters have moved away from their start at 1 (k_mm_split)
+            const bool split = g_mm_split < 0 ? it >= TCLIP_SPLIT_FROM : (g_mm_split >= 100 ? it >= g_mm_split - 100 : g_mm_split != 0);
+            const bool split_runs = split && mm_has_split(K);
+            a.work_counter = g_prof.on ? g_prof.counter + (split_runs ? 1 : 0) : nullptr;
             hipEvent_t e0 = g_prof.on ? prof_event() : nullptr, e1 = g_prof.on ? prof_event() : nullptr;
             if (e0 && e1) TCLIP_HIP(hipEventRecord(e0, st));
             a.rows = live_rows; a.n_rows = counts + 1;
-            // class-split kernel once the parameters have moved away from their start at 1 (k_mm_split)
-            const bool split = g_mm_split < 0 ? it >= TCLIP_SPLIT_FROM : (g_mm_split >= 100 ? it >= g_mm_split - 100 : g_mm_split != 0);
+            g_last_mm_was_split = false;
             launch_mm(split ? kMMSplit : kMMLive, K, TK, st, a);
-            if (e0 && e1) TCLIP_HIP(hipEventRecord(e1, st));    // the instrumentation covers k_mm_live / k_mm_split only
+            if (e0 && e1) {                                     // the instrumentation covers k_mm_live / k_mm_split only
+                TCLIP_HIP(hipEventRecord(e1, st));
+                if (g_prof.kind.size() < g_prof.used / 2) g_prof.kind.resize(g_prof.used / 2);
+                g_prof.kind[g_prof.used / 2 - 1] = g_last_mm_was_split ? 1 : 0;
+            }
+            if (split_runs != g_last_mm_was_split) return fail(TCLIP_ERR_ARG, "internal: mm_has_split disagrees with launch_mm");
             if (zs && a.has_check) {          // dead rows only matter through their stop-test terms
                 a.rows = dead_list[c & 1]; a.n_rows = dead_counts + c; a.work_counter = nullptr;
                 // the probe needs the row to be ON its cycle already; rows that were still approaching
@@ -3409,27 +3454,15 @@ int tclip_debug_set_probe_chunks(int32_t chunks) {
 
 int tclip_profile_enable(int on) {
     if (on && !g_prof.counter) {
-        TCLIP_HIP(hipMalloc((void**)&g_prof.counter, sizeof(unsigned long long)));
-        TCLIP_HIP(hipMemset(g_prof.counter, 0, sizeof(unsigned long long)));
+        TCLIP_HIP(hipMalloc((void**)&g_prof.counter, 2 * sizeof(unsigned long long)));
+        TCLIP_HIP(hipMemset(g_prof.counter, 0, 2 * sizeof(unsigned long long)));
     }
     g_prof.on = on != 0;
     return TCLIP_OK;
 }
 
-int tclip_profile_collect(double* mm_busy_ms, double* mm_launch_ms_sum, int64_t* mm_launches,
-                          int64_t* element_updates) {
-    TCLIP_HIP(hipDeviceSynchronize());
-    // launches of different batch groups overlap on their streams: report both the sum of the
-    // individual launch durations and the length of the union of the [start, end] intervals
-    std::vector<std::pair<float, float>> iv;
-    double sum = 0.0;
-    for (size_t i = 0; i + 1 < g_prof.used; i += 2) {
-        float t0 = 0.f, t1 = 0.f;
-        TCLIP_HIP(hipEventElapsedTime(&t0, g_prof.ev[0], g_prof.ev[i]));
-        TCLIP_HIP(hipEventElapsedTime(&t1, g_prof.ev[0], g_prof.ev[i + 1]));
-        iv.emplace_back(t0, t1);
-        sum += (double)t1 - (double)t0;
-    }
+// length of the union of intervals
+static double union_ms(std::vector<std::pair<float, float>>& iv) {
     std::sort(iv.begin(), iv.end());
     double busy = 0.0, cur_lo = 0.0, cur_hi = -1.0;
     for (auto& x : iv) {
@@ -3442,16 +3475,50 @@ int tclip_profile_collect(double* mm_busy_ms, double* mm_launch_ms_sum, int64_t*
         }
     }
     if (cur_hi >= cur_lo) busy += cur_hi - cur_lo;
+    return busy;
+}
+int tclip_profile_collect(double* mm_busy_ms, double* mm_launch_ms_sum, int64_t* mm_launches,
+                          int64_t* element_updates) {
+    TCLIP_HIP(hipDeviceSynchronize());
+    // launches of different batch groups overlap on their streams: report both the sum of the
+    // individual launch durations and the length of the union of the [start, end] intervals
+    std::vector<std::pair<float, float>> iv, ivk[2];
+    double sum = 0.0;
+    for (int k = 0; k < 2; k++) { g_prof.last_sum[k] = 0.0; g_prof.last_launches[k] = 0; }
+    for (size_t i = 0; i + 1 < g_prof.used; i += 2) {
+        float t0 = 0.f, t1 = 0.f;
+        TCLIP_HIP(hipEventElapsedTime(&t0, g_prof.ev[0], g_prof.ev[i]));
+        TCLIP_HIP(hipEventElapsedTime(&t1, g_prof.ev[0], g_prof.ev[i + 1]));
+        iv.emplace_back(t0, t1);
+        sum += (double)t1 - (double)t0;
+        const int k = i / 2 < g_prof.kind.size() ? g_prof.kind[i / 2] : 0;
+        ivk[k].emplace_back(t0, t1);
+        g_prof.last_sum[k] += (double)t1 - (double)t0;
+        g_prof.last_launches[k]++;
+    }
+    const double busy = union_ms(iv);
+    for (int k = 0; k < 2; k++) g_prof.last_busy[k] = union_ms(ivk[k]);
     if (mm_busy_ms) *mm_busy_ms = busy;
     if (mm_launch_ms_sum) *mm_launch_ms_sum = sum;
     if (mm_launches) *mm_launches = (int64_t)(g_prof.used / 2);
-    unsigned long long c = 0;
+    unsigned long long c[2] = {0, 0};
     if (g_prof.counter) {
-        TCLIP_HIP(hipMemcpy(&c, g_prof.counter, sizeof c, hipMemcpyDeviceToHost));
+        TCLIP_HIP(hipMemcpy(c, g_prof.counter, sizeof c, hipMemcpyDeviceToHost));
         TCLIP_HIP(hipMemset(g_prof.counter, 0, sizeof c));
     }
-    if (element_updates) *element_updates = (int64_t)c;
+    g_prof.last_updates[0] = (int64_t)c[0];
+    g_prof.last_updates[1] = (int64_t)c[1];
+    if (element_updates) *element_updates = (int64_t)(c[0] + c[1]);
     g_prof.used = 0;
+    return TCLIP_OK;
+}
+int tclip_profile_last_kernels(double* busy_ms, double* launch_ms_sum, int64_t* launches, int64_t* element_updates) {
+    for (int k = 0; k < 2; k++) {
+        if (busy_ms) busy_ms[k] = g_prof.last_busy[k];
+        if (launch_ms_sum) launch_ms_sum[k] = g_prof.last_sum[k];
+        if (launches) launches[k] = g_prof.last_launches[k];
+        if (element_updates) element_updates[k] = g_prof.last_updates[k];
+    }
     return TCLIP_OK;
 }
 

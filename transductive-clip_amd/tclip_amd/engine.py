@@ -353,3 +353,11 @@ def profile_collect():
     _capi.check(_capi.lib().tclip_profile_collect(ctypes.byref(busy), ctypes.byref(total), ctypes.byref(n),
                                                   ctypes.byref(upd)), "tclip_profile_collect")
     return busy.value, total.value, n.value, upd.value
+
+
+def profile_last_kernels():
+    """{'k_mm_live': (busy_ms, launch_ms_sum, launches, element_updates), 'k_mm_split': (...)} of the last profile_collect()"""
+    busy, total = (ctypes.c_double * 2)(), (ctypes.c_double * 2)()
+    n, upd = (ctypes.c_int64 * 2)(), (ctypes.c_int64 * 2)()
+    _capi.check(_capi.lib().tclip_profile_last_kernels(busy, total, n, upd), "tclip_profile_last_kernels")
+    return {name: (busy[i], total[i], n[i], upd[i]) for i, name in enumerate(("k_mm_live", "k_mm_split"))}
