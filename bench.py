@@ -261,11 +261,30 @@ def main():
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     if dist_on:
+        import contextlib
         import torch.distributed as dist
-        if args.backend == "nccl":
-            dist.init_process_group("nccl", device_id=dev)
-        else:
-            dist.init_process_group(args.backend)
+
+        @contextlib.contextmanager
+        def stdout_to_stderr():
+            """librccl prints a version banner on the process's stdout (fd 1) when its first communicator comes up; the
+            contract of this script is ONE JSON line on stdout, so fd 1 points at stderr while RCCL initialises"""
+            sys.stdout.flush()
+            keep = os.dup(1)
+            os.dup2(2, 1)
+            try:
+                yield
+            finally:
+                sys.stdout.flush()
+                os.dup2(keep, 1)
+                os.close(keep)
+
+        with stdout_to_stderr():
+            if args.backend == "nccl":
+                dist.init_process_group("nccl", device_id=dev)
+            else:
+                dist.init_process_group(args.backend)
+            dist.barrier()                               # the communicator (and its banner) comes up here at the latest
+            torch.cuda.synchronize()
         if dist.get_world_size() != args.gpus:
             raise SystemExit(f"--gpus {args.gpus} but the launcher started {dist.get_world_size()} ranks")
 

@@ -368,3 +368,27 @@ def test_kmeans_tile_kernel_is_invisible(K):
         ref = c_oracle.run_soft_kmeans(x_q.numpy(), iters=6, temperature=30)
         u, w, _ = out[-1][0]
         assert np.array_equal(u.cpu().numpy(), ref["u"]) and np.array_equal(w.cpu().numpy(), ref["w"])
+
+
+def test_bench_prints_one_json_line_under_rccl():
+    """bench.py under the driver's launcher with the nccl (= RCCL) backend, one rank: librccl prints a version banner on the
+    process's stdout when its communicator comes up; the script keeps fd 1 on stderr meanwhile, so that stdout carries the
+    ONE JSON line of the contract and nothing else - with `rank_devices` (one GPU per rank) on it."""
+    import json
+    import subprocess
+    import sys
+    from conftest import ROOT
+    port = 29900 + os.getpid() % 90
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "1", "--warmup", "0",
+           "--workload", "k100", "--no-secondary", "--no-cpu-baseline"]
+    out = subprocess.run(cmd, capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stderr[-2000:]
+    lines = [l for l in out.stdout.splitlines() if l.strip()]
+    assert len(lines) == 1 and lines[0].startswith("{"), out.stdout[:2000]
+    d = json.loads(lines[0])
+    assert d["backend"] == "nccl" and d["ranks_seen"] == 1 and d["rank_devices"] == [0]
+    assert set(d["roofline"]["per_kernel"]) == {"k_mm_live", "k_mm_split"}
+    # a launcher whose world size differs from --gpus is refused
+    bad = subprocess.run(cmd[:cmd.index("--gpus") + 1] + ["2"] + cmd[cmd.index("--gpus") + 2:], capture_output=True, text=True, timeout=600)
+    assert bad.returncode != 0 and "--gpus 2" in (bad.stderr + bad.stdout)
