@@ -291,6 +291,14 @@ def main():
     import random
 
     import numpy as np
+    if dist_on:
+        # N ranks prepare the same synthetic table at the same time (200 MB of randn + softmax at K = 1000): each keeps to its
+        # share of the host's cores instead of N x all of them
+        try:
+            usable = len(os.sched_getaffinity(0))
+        except AttributeError:
+            usable = os.cpu_count() or 1
+        torch.set_num_threads(max(1, usable // max(1, int(os.environ.get("LOCAL_WORLD_SIZE", world)))))
     from src.eval_zero_shot import Evaluator_zero_shot
     from src.utils import CfgNode
     from tclip_amd import engine, sharding, synth
