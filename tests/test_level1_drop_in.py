@@ -218,3 +218,62 @@ def test_level1_copied_classes_run_without_this_repos_src(tmp_path):
     r = run_block(str(tree), "probe_main.py", run_build=False)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
     assert "LEVEL1-GPU-OK zs_soft_K10_N4,zs_hard_K37_N6,fs_soft_K37_N3_s2,fs_hard_K10_N4_s4" in r.stdout
+
+
+_PROBE_ALL_METHODS = _STUBS + r"""
+import glob, shutil, torch
+HERE = os.path.dirname(os.path.abspath(__file__))
+TCLIP = {pkg!r}
+# every method module this repo provides, copied over the reference's (the document's `cp` pattern, all of them)
+copied = []
+for src_file in sorted(glob.glob(os.path.join(TCLIP, "drop_in", "src", "methods", "*", "*.py")) +
+                       [os.path.join(TCLIP, "drop_in", "src", "methods", "_em_dirichlet_base.py")]):
+    rel = os.path.relpath(src_file, os.path.join(TCLIP, "drop_in"))
+    if os.path.basename(rel) == "__init__.py":
+        continue
+    shutil.copyfile(src_file, os.path.join(HERE, rel))
+    copied.append(rel)
+exec("\n".join(open(os.path.join(HERE, "main.py")).read().splitlines()[9:12]))
+import src.utils
+
+
+class Args(dict):
+    __getattr__ = dict.__getitem__
+    __setattr__ = dict.__setitem__
+
+
+built = []
+zs = ["KL_KMEANS", "EM_DIRICHLET", "HARD_EM_DIRICHLET", "EM_GAUSSIAN", "EM_GAUSSIAN_COV", "SOFT_KMEANS", "HARD_KMEANS", "CLIP"]
+fs = ["EM_DIRICHLET", "HARD_EM_DIRICHLET", "PADDLE", "BDCSPN", "ALPHA_TIM", "LAPLACIAN_SHOT"]
+for Ev, names in ((Evaluator_zero_shot, zs), (Evaluator_few_shot, fs)):
+    for name in names:
+        args = Args(iter=3, iter_mm=50, num_classes_test=10, n_class=10, n_query=75, k_eff=5, T=30, shots=2, use_softmax_feature=True,
+                    graph_matching=True, name_method=name, used_test_set="test", tunable=False, lambd=0.0, number_tasks=2, batch_size=2,
+                    dataset="synthetic", norm_type="L2N", temp=15.0, num_NN=1, knn=3, lmd=0.7, loss_weights=[1.0, 1.0, 1.0],
+                    lr_alpha_tim=1e-4, entropies=["Shannon", "Alpha", "Alpha"], alpha_value=7.0)
+        log = os.path.join(HERE, "probe.log")
+        ev = Ev(device=torch.device("cpu"), args=args, log_file=log)
+        m = ev.get_method_builder(model=None, device=torch.device("cpu"), args=args, log_file=log)
+        mod = sys.modules[type(m).__module__]
+        assert type(m).__name__ == name, (name, type(m))
+        assert mod.__file__.startswith(os.path.join(HERE, "src", "methods")), mod.__file__
+        assert "tclip_amd" in open(mod.__file__).read() or "_em_dirichlet_base" in open(mod.__file__).read(), mod.__file__
+        built.append(name)
+assert src.utils.__file__ == os.path.join(HERE, "src", "utils.py")
+print("LEVEL1-ALL-OK", len(copied), ",".join(built))
+"""
+
+
+@pytest.mark.skipif(not os.path.isdir(REF), reason="the reference checkout exists in the build container only")
+def test_every_method_module_overlays_the_reference(tmp_path):
+    """the widened methods (k-means family, EM_GAUSSIAN(_COV), CLIP, PADDLE, BDCSPN, ALPHA_TIM, LAPLACIAN_SHOT) drop in the same
+    way: all of drop_in/src/methods/ copied over a copy of the reference, main.py:10-12's imports, and every method both of the
+    reference's evaluators can build comes from the copied modules."""
+    ref = tmp_path / "reference"
+    shutil.copytree(REF, ref, ignore=shutil.ignore_patterns("__pycache__", "figures", "results_few_shot", ".git"))
+    (ref / "probe_all.py").write_text(_PROBE_ALL_METHODS.format(pkg=PKG))
+    env = {k: v for k, v in os.environ.items() if k != "PYTHONPATH"}
+    env["PYTHONPATH"] = PKG
+    r = subprocess.run([sys.executable, "probe_all.py"], cwd=str(ref), env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
+    assert "LEVEL1-ALL-OK 15 " in r.stdout and r.stdout.strip().endswith("LAPLACIAN_SHOT"), r.stdout[-500:]
