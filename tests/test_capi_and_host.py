@@ -179,3 +179,37 @@ def test_widened_method_classes_have_no_cpu_path():
         m = cls(model=None, device=torch.device("cpu"), log_file=None, args=a)
         with pytest.raises(RuntimeError, match="no CPU fallback"):
             m.run_task(dict(fs_task), shot=1)
+
+
+def test_source_digest_ignores_comments_not_code(tmp_path, monkeypatch):
+    """profiles/pmc_current.json is tied to the kernel sources by _capi.source_digest(): a comment or blank line may change,
+    a token may not; and the committed PMC entries describe the tree as it is (bench.py reports their traffic / clock)."""
+    import json
+    import shutil
+    assert _capi._strip_comments('int a = 1; // c\n/* b\n c */ const char* s = "// no /* no */";\n\n   \n') == \
+        'int a = 1;\n const char* s = "// no /* no */";'
+    csrc = os.path.join(os.path.dirname(_capi._HERE), "csrc")
+    fake = tmp_path / "pkg"
+    shutil.copytree(csrc, fake / "csrc")
+    (fake / "tclip_amd").mkdir()
+    monkeypatch.setattr(_capi, "_HERE", str(fake / "tclip_amd"))
+    base = _capi.source_digest()
+    f = fake / "csrc" / "tclip_pk.h"
+    text = f.read_text()
+    f.write_text("// a new remark\n\n" + text.replace("// RN(1/x), see rcp_rn_f32", "// RN(1/x)  (reworded)"))
+    assert _capi.source_digest() == base
+    f.write_text(text.replace("pk_fma(e, r, r)", "pk_fma(e, r, e)"))
+    assert _capi.source_digest() != base
+    monkeypatch.undo()
+    # bench.py reports the committed PMC figures only for the kernel sources they were taken on
+    import sys
+    sys.path.insert(0, ROOT)
+    import bench
+    pmc = json.load(open(os.path.join(ROOT, "profiles", "pmc_current.json")))
+    assert set(pmc) == {"k1000", "k100", "k397_hard", "fs_k1000"}
+    monkeypatch.setattr(bench._capi, "source_digest", lambda: pmc["k1000"]["csrc_sha1"])
+    fresh = bench.roofline_of((10.0, 10.0, 4, 10 ** 9), 1, 1000, "k1000")
+    assert fresh["traffic"] == pmc["k1000"]["traffic_bytes_per_launch"] and "pmc_stale" not in fresh and fresh["measured_clock_ghz"] > 1.0
+    monkeypatch.setattr(bench._capi, "source_digest", lambda: "0" * 40)
+    stale = bench.roofline_of((10.0, 10.0, 4, 10 ** 9), 1, 1000, "k1000")
+    assert stale["traffic"] is None and "measured_clock_ghz" not in stale and stale["pmc_stale"]["file"] == pmc["k1000"]["file"]

@@ -4,6 +4,7 @@
 // Stream of one outer iteration (reference: src/methods/zero_shot/em_dirichlet.py:214-244):
 //   k_cluster_sizes   cs = sum_q u, live mask, v                                   (:217-218, :151)
 //   k_mstats          y = u^T log z / cs  (+ support statistics in few-shot)       (:219-222)
+//                     (k_mstats_cols75 for the reference's 75 queries: 64 feature columns staged once per block)
 //   k_build_rows      compact the rows that must iterate: live rows; dead rows whose stop-test
 //                     contributions are not cached yet
 //   k_mm_live x20     <=50 majorize-minimize iterations per launch for the live rows, alpha rows
@@ -18,10 +19,12 @@
 //
 // The other methods behind the same boundary reuse k_cluster_sizes, k_mstats*,
 // k_softmax and add:
-//   k_kmeans_logits_rows   squared distances to the centroids (SOFT/HARD_KMEANS, EM_GAUSSIAN, PADDLE, BDCSPN)
+//   k_kmeans_logits_tile / k_kmeans_logits_rows   squared distances to the centroids (SOFT/HARD_KMEANS, EM_GAUSSIAN, PADDLE,
+//                     BDCSPN): one lane per class on a 64-centroid LDS tile (rows of 32 .. 511 elements) / 32 lanes per class
 //   k_mstats*<true>, k_cov_logits_rows   inverse diagonal covariances, Mahalanobis + log-det logits (EM_GAUSSIAN_COV)
 //   k_kl_centroids, k_kl_divergences, k_argmin_rows, k_hard_assign   KL_KMEANS / HARD_KMEANS assignment
 //   k_support_stats, k_div_rows   support class means (few-shot EM-Dirichlet, PADDLE, BDCSPN)
+//   k_gather_log_features   u = z and log z read from a feature table through index tensors (tclip_em_dirichlet_run_tasks)
 //   k_col_mean, k_bdcspn_normalize, k_bdcspn_eta   BD-CSPN normalisation (torch's norm order) and query shift
 //   k_argmax_rows   inductive CLIP baseline
 #include <hip/hip_runtime.h>

@@ -95,17 +95,41 @@ def lib():
     return _lib
 
 
+def _strip_comments(text):
+    """C / C++ source without comments and without blank or all-space lines (string and character literals kept intact)"""
+    out, i, n = [], 0, len(text)
+    while i < n:
+        c = text[i]
+        if c == '"' or c == "'":                       # literal: copy to its closing quote
+            j = i + 1
+            while j < n and text[j] != c:
+                j += 2 if text[j] == "\\" else 1
+            out.append(text[i:j + 1])
+            i = j + 1
+        elif text.startswith("//", i):
+            j = text.find("\n", i)
+            i = n if j < 0 else j
+        elif text.startswith("/*", i):
+            j = text.find("*/", i + 2)
+            i = n if j < 0 else j + 2
+        else:
+            out.append(c)
+            i += 1
+    return "\n".join(ln.rstrip() for ln in "".join(out).split("\n") if ln.strip())
+
+
 def source_digest():
-    """sha1 over the kernel sources (csrc/*.hip, *.h, *.inc, *.cpp, in name order): what a committed profile was taken on.
-    profiles/pmc_current.json stores it and bench.py reports the PMC-derived fields only while it matches the tree."""
+    """sha1 over the kernel sources (csrc/*.hip, *.h, *.inc, *.cpp, in name order) with comments and blank lines removed:
+    what a committed profile was taken on.  profiles/pmc_current.json stores it and bench.py reports the PMC-derived fields
+    only while it matches the tree; editing a comment does not invalidate a measurement, editing code does."""
     import hashlib
     csrc = os.path.join(os.path.dirname(_HERE), "csrc")
     h = hashlib.sha1()
     for name in sorted(os.listdir(csrc)):
         if name.endswith((".hip", ".h", ".inc", ".cpp")):
             h.update(name.encode())
-            with open(os.path.join(csrc, name), "rb") as f:
-                h.update(f.read())
+            with open(os.path.join(csrc, name), "r", encoding="utf-8", errors="replace") as f:
+                h.update(_strip_comments(f.read()).encode())
     return h.hexdigest()
 
 
