@@ -976,9 +976,6 @@ __global__ __launch_bounds__(64 * W, (E > 16 ? TCLIP_MM_WAVES_LARGE : TCLIP_MM_W
 #ifndef TCLIP_SPLIT_WAVES_MID
 #define TCLIP_SPLIT_WAVES_MID 4    // wavefronts per SIMD requested for 9..16 registers per lane
 #endif
-#ifndef TCLIP_SPLIT_OPAQUE_PLANE1
-#define TCLIP_SPLIT_OPAQUE_PLANE1 0
-#endif
 #ifndef TCLIP_SPLIT_MIN_E
 #define TCLIP_SPLIT_MIN_E 5        // shorter rows fill too little of a dense pass: measured with 16 lanes per row on 1000 tasks,
                                    // split against k_mm_live: K = 10 +42 %, 37 +6 %, 47 +7 %, 64 +1 %, 80 -4.5 %, 96 -5 %, 100 -11 %,
@@ -1223,17 +1220,7 @@ __device__ __forceinline__ void mm_iterate_wave_split(float (&beta)[E], const Ro
     }
     // phase C
     wave_lds_handoff();
-#if TCLIP_SPLIT_OPAQUE_PLANE1
-    {   // plane 1 through a pointer the compiler cannot relate to plane 0: it then fetches the two lgamma words of a register
-        // pair into one register pair and the two digamma words into another (four ds_read_b32) instead of merging the
-        // (lgamma, digamma) words of each element into a ds_read2st64 and transposing them with three v_mov per pair
-        const float* p1 = my1;
-        asm volatile("" : "+v"(p1));
-        split_apply_updates<E, G>(beta, yv, K, lane, psi_s, my0, p1, slot, measure, num, den);
-    }
-#else
     split_apply_updates<E, G>(beta, yv, K, lane, psi_s, my0, my1, slot, measure, num, den);
-#endif
     wave_lds_handoff();
 }
 
