@@ -343,8 +343,8 @@ def test_table_fed_entry_equals_materialised_tensors(K, N, B, shots, perm, hard)
 @pytest.mark.parametrize("K", [32, 33, 40, 47, 63, 64, 65, 96, 100, 127, 128, 129, 196, 255, 256, 257, 397, 448, 449, 511])
 def test_kmeans_tile_kernel_is_invisible(K):
     """k_kmeans_logits_tile (one lane per class on a 64-centroid LDS tile, rows of 32 .. 511 elements) against
-    k_kmeans_logits_rows (32 lanes per class) through SOFT_KMEANS, HARD_KMEANS and PADDLE: identical u, centroids and
-    predictions - row lengths with every K mod 32 structure (no / one / three leftover vectors, tails of 0 .. 7, the tile
+    k_kmeans_logits_rows (32 lanes per class) through SOFT_KMEANS, HARD_KMEANS and PADDLE, and k_kl_divergences_tile against
+    k_kl_divergences through KL_KMEANS: identical u, centroids and predictions - row lengths with every K mod 32 structure (no / one / three leftover vectors, tails of 0 .. 7, the tile
     edges 64 k and 64 k + 1); the smaller ones also against the C++ oracle."""
     from oracle import c_oracle
     from tclip_amd import _capi, engine, synth
@@ -357,7 +357,7 @@ def test_kmeans_tile_kernel_is_invisible(K):
         for mode in (0, -1):
             _capi.check(_capi.lib().tclip_debug_set_kmeans_tile(mode), "tclip_debug_set_kmeans_tile")
             out[mode] = (engine.run_soft_kmeans(x, iters=6, temperature=30), engine.run_hard_kmeans(x, iters=4),
-                         engine.run_paddle(x, xs, ys, iters=5, lambd=2.5))
+                         engine.run_paddle(x, xs, ys, iters=5, lambd=2.5), engine.run_kl_kmeans(x, iters=4))
             torch.cuda.synchronize()
     finally:
         _capi.lib().tclip_debug_set_kmeans_tile(-1)

@@ -2058,6 +2058,92 @@ __global__ __launch_bounds__(256) void k_kl_divergences(const float* __restrict_
     }
 }
 
+// KL divergences with one lane per class (round 4), the structure of k_kmeans_logits_tile: the tile holds Q = w + eps of 64
+// centroids, the wavefront's query row P = z + eps is wave-uniform (scalar loads), a lane keeps torch's 32 partial sums of
+// sum_d P log(P / Q) for its class.  Per (query, class, d): the short exact quotient, the restated MKL logarithm (its three
+// tables in LDS), one multiply, one add - and nothing across lanes (k_kl_divergences: ~25 cross-lane instructions per 32-lane
+// sum, each query row re-read per four classes).  A step whose 32 elements are not all inside the range of the fast forms
+// (wave-uniform test) takes the IEEE quotient and log_f32, which agree with the fast forms wherever those are defined.
+// z + 1e-15 lies inside the fast forms' range (positive normal, |exponent| <= 60) whenever z itself is +0 .. 2^60: a test on
+// the bits of the wave-uniform z, i.e. on the scalar unit (sufficient, not necessary: anything else takes the generic forms)
+__device__ __forceinline__ bool kl_p_surely_fast(float z) { return f32_bits(z) <= 0x5d800000u; }
+__global__ __launch_bounds__(TCLIP_KMEANS_TILE_THREADS) void k_kl_divergences_tile(const float* __restrict__ w, const float* __restrict__ z,
+                                                                                  int Q, int K, int stride, float* __restrict__ divs) {
+    extern __shared__ float wt[];                                   // [kKmeansTile][stride]: w + eps
+    __shared__ uint32_t s_buckets[64];
+    __shared__ float s_t1[32], s_t2[32];
+    const int t = blockIdx.y, k0 = blockIdx.x * kKmeansTile;
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), n_waves = blockDim.x >> 6;
+    const int k = k0 + lane;
+    if (threadIdx.x < 64) s_buckets[threadIdx.x] = kRcp14Buckets.e[threadIdx.x];
+    if (threadIdx.x < 32) { s_t1[threadIdx.x] = kSlnT1[threadIdx.x]; s_t2[threadIdx.x] = kSlnT2[threadIdx.x]; }
+    const int rows = K - k0 < kKmeansTile ? K - k0 : kKmeansTile;
+    const float* wsrc = w + ((size_t)t * K + k0) * K;
+    bool q_in = true;
+    {
+        const int n = rows * K, step = blockDim.x;
+        const int pad = stride - K;
+        for (int i0 = threadIdx.x; i0 < n; i0 += 8 * step) {
+            float v[8];
+#pragma unroll
+            for (int j = 0; j < 8; j++) v[j] = i0 + j * step < n ? wsrc[i0 + j * step] + kEpsF : 1.0f;
+#pragma unroll
+            for (int j = 0; j < 8; j++) {
+                const int i = i0 + j * step;
+                q_in = q_in && fast_range_f32(v[j]);
+                if (i < n) wt[i + (pad ? i / K : 0)] = v[j];
+            }
+        }
+    }
+    const bool q_ok = __syncthreads_and(q_in);                      // every Q of the tile inside the fast forms' range
+    const float* wl = wt + (lane < rows ? lane : rows - 1) * stride;
+    const int vec_size = K >> 3, size_ilp = vec_size >> 2, nleft = vec_size - 4 * size_ilp, ntail = K - 8 * vec_size;
+    auto term_fast = [&](float pz, float qv) {
+        const float P = pz + kEpsF;
+        return P * log_mkl_inrange_tab(div_rn_inrange_f32(P, qv), s_buckets, s_t1, s_t2);
+    };
+    auto term_any = [&](float pz, float qv) {
+        const float P = pz + kEpsF;
+        return P * log_f32(P / qv);
+    };
+    auto term = [&](float pz, float qv, bool fast) { return fast ? term_fast(pz, qv) : term_any(pz, qv); };
+    for (int q = wave; q < Q; q += n_waves) {
+        const float* zq = z + ((size_t)t * Q + q) * K;              // wave-uniform: scalar loads
+        float acc[32];
+#pragma unroll
+        for (int sl = 0; sl < 32; sl++) acc[sl] = 0.0f;
+        for (int m = 0; m < size_ilp; m++) {
+            bool p_in = true;
+#pragma unroll
+            for (int sl = 0; sl < 32; sl++) p_in = p_in && kl_p_surely_fast(zq[32 * m + sl]);
+            if (q_ok && p_in) {                                     // wave-uniform (the row is): one straight block of fast forms
+#pragma unroll
+                for (int sl = 0; sl < 32; sl++) acc[sl] += term_fast(zq[32 * m + sl], wl[32 * m + sl]);
+            } else {
+#pragma unroll
+                for (int sl = 0; sl < 32; sl++) acc[sl] += term_any(zq[32 * m + sl], wl[32 * m + sl]);
+            }
+        }
+        int d = 32 * size_ilp;
+        for (int i = 0; i < nleft; i++, d += 8) {
+#pragma unroll
+            for (int j = 0; j < 8; j++) acc[j] += term(zq[d + j], wl[d + j], q_ok && kl_p_surely_fast(zq[d + j]));
+        }
+        float fin = 0.0f;
+        for (int i = 0; i < ntail; i++) fin += term(zq[d + i], wl[d + i], q_ok && kl_p_surely_fast(zq[d + i]));
+#pragma unroll
+        for (int j = 0; j < 8; j++) {
+            float p0 = acc[j];
+            p0 += acc[8 + j];
+            p0 += acc[16 + j];
+            p0 += acc[24 + j];
+            fin += p0;
+        }
+        if (k < K) divs[((size_t)t * Q + q) * K + k] = fin;
+    }
+}
+
 // labels[r] = first index of the smallest of the K values of row r (torch.argmin).
 __global__ void k_argmin_rows(const float* __restrict__ x, int rows, int K, int32_t* __restrict__ labels) {
     const int r = blockIdx.x * blockDim.x + threadIdx.x;
@@ -2565,15 +2651,21 @@ template <int E> struct LaunchKmeansLogitsRows {
 
 static int g_kmeans_tile = -1;       // tclip_debug_set_kmeans_tile: 0 = k_kmeans_logits_rows for every K, negative: the default rule
 // squared distances to the centroids: one lane per class where the row length allows it (k_kmeans_logits_tile), else 32 lanes per class
+// the tile kernels' dynamic LDS goes beyond the 64 KB a kernel gets without asking (once per kernel and process)
+static bool kmeans_tile_lds_raised(const void* kernel) {
+    static std::vector<std::pair<const void*, bool>> seen;
+    for (auto& e : seen)
+        if (e.first == kernel) return e.second;
+    const bool ok = hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, kKmeansTile * 511 * (int)sizeof(float)) == hipSuccess;
+    seen.emplace_back(kernel, ok);
+    return ok;
+}
 static void launch_kmeans_logits(int T, hipStream_t st, const float* w, const float* z, const uint8_t* need, int Q, int K, float pre,
                                  float temperature, float* logit0) {
     if (g_kmeans_tile != 0 && K >= 32 && K <= 511) {
         const int stride = K | 1;
         const size_t lds = (size_t)kKmeansTile * stride * sizeof(float);
-        static const bool raised = [] {                               // beyond the 64 KB a kernel gets without asking
-            return hipFuncSetAttribute((const void*)k_kmeans_logits_tile, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                       kKmeansTile * 511 * (int)sizeof(float)) == hipSuccess;
-        }();
+        const bool raised = kmeans_tile_lds_raised((const void*)k_kmeans_logits_tile);
         if (raised) {
             hipLaunchKernelGGL(k_kmeans_logits_tile, dim3((K + kKmeansTile - 1) / kKmeansTile, T), dim3(kKmeansTileThreads), lds, st, w, z, need, Q, K,
                                stride, pre, temperature, logit0);
@@ -3391,7 +3483,13 @@ int tclip_kl_kmeans_run(const tclip_problem* pp, const float* x_q, float* u, flo
                            live, (float*)nullptr, (int32_t*)nullptr);
         hipLaunchKernelGGL(k_kl_centroids, dim3((K + 63) / 64, (K + kMstatsRows - 1) / kMstatsRows, T), dim3(64), 0, st,
                            (const float*)u, x_q, (const float*)cs, Q, K, w);
-        dispatch_E<LaunchKlDivergences>(K, T, st, (const float*)w, x_q, Q, K, divs);
+        if (g_kmeans_tile != 0 && K >= 32 && K <= 511 && kmeans_tile_lds_raised((const void*)k_kl_divergences_tile)) {
+            const int stride = K | 1;
+            hipLaunchKernelGGL(k_kl_divergences_tile, dim3((K + kKmeansTile - 1) / kKmeansTile, T), dim3(kKmeansTileThreads),
+                               (size_t)kKmeansTile * stride * sizeof(float), st, (const float*)w, x_q, Q, K, stride, divs);
+        } else {
+            dispatch_E<LaunchKlDivergences>(K, T, st, (const float*)w, x_q, Q, K, divs);
+        }
         hipLaunchKernelGGL(k_argmin_rows, dim3((T * Q + 255) / 256), dim3(256), 0, st, (const float*)divs, T * Q, K, preds);
         hipLaunchKernelGGL(k_hard_assign, dim3(T), dim3(256), 0, st, (const int32_t*)preds, Q, K, u, change);
         hipLaunchKernelGGL(k_criterion_mean, dim3(B), dim3(64), 0, st, (const float*)change, N, 0, criterions + it, p.iters);
