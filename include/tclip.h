@@ -293,9 +293,10 @@ int tclip_debug_set_rowset_min_rows(int32_t rows);
  * results do not depend on it. */
 int tclip_debug_set_mm_split(int32_t mode);
 
-/* The squared distances of the k-means family (SOFT/HARD_KMEANS, EM_GAUSSIAN, PADDLE, BD-CSPN) run one lane per class on a
- * 64-centroid tile staged in LDS for rows of 32 .. 511 elements (k_kmeans_logits_tile), 32 lanes per class otherwise.  For
- * tests: 0 uses the 32-lane kernel for every row length, negative restores the default rule.  Process-wide; results do not
+/* The squared distances of the k-means family (SOFT/HARD_KMEANS, EM_GAUSSIAN, PADDLE, BD-CSPN) and KL_KMEANS's divergences run one
+ * lane per class on a 64-centroid tile staged in LDS for rows of 32 .. 511 elements (k_kmeans_logits_tile, k_kl_divergences_tile),
+ * 32 lanes per class otherwise; the centroid statistics of 75-query problems stage 64 feature columns per block (k_mstats_cols75).  For
+ * tests: 0 uses the round-3 kernels for every shape, negative restores the default rule.  Process-wide; results do not
  * depend on it. */
 int tclip_debug_set_kmeans_tile(int32_t mode);
 
