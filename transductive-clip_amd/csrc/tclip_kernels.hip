@@ -34,6 +34,7 @@
 #include <string.h>
 
 #include <algorithm>
+#include <mutex>
 #include <utility>
 #include <vector>
 
@@ -2653,11 +2654,16 @@ static int g_kmeans_tile = -1;       // tclip_debug_set_kmeans_tile: 0 = k_kmean
 // squared distances to the centroids: one lane per class where the row length allows it (k_kmeans_logits_tile), else 32 lanes per class
 // the tile kernels' dynamic LDS goes beyond the 64 KB a kernel gets without asking (once per kernel and process)
 static bool kmeans_tile_lds_raised(const void* kernel) {
-    static std::vector<std::pair<const void*, bool>> seen;
+    struct Seen { const void* kernel; int device; bool ok; };
+    static std::mutex mu;                                     // entry points are re-entrant across host threads
+    static std::vector<Seen> seen;
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess) return false;
+    std::lock_guard<std::mutex> lock(mu);
     for (auto& e : seen)
-        if (e.first == kernel) return e.second;
+        if (e.kernel == kernel && e.device == dev) return e.ok;
     const bool ok = hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, kKmeansTile * 511 * (int)sizeof(float)) == hipSuccess;
-    seen.emplace_back(kernel, ok);
+    seen.push_back(Seen{kernel, dev, ok});
     return ok;
 }
 static void launch_kmeans_logits(int T, hipStream_t st, const float* w, const float* z, const uint8_t* need, int Q, int K, float pre,
@@ -2762,6 +2768,59 @@ __global__ __launch_bounds__(64 * kColsWaves) void k_mstats_cols75(const float* 
             } else {
                 y[row * K + d] = s / (c < kEpsF ? kEpsF : c);
             }
+        }
+    }
+}
+
+// KL_KMEANS's centroids (k_kl_centroids) in the same blocking: one chain of fused multiply-adds per output over the 75
+// queries in ascending order (what MKL's sgemm does for these shapes), 64 feature columns staged once per block, u as scalar
+// loads.  Q * K * K >= 400 here (K >= 8), i.e. always the fused form.
+__global__ __launch_bounds__(64 * kColsWaves) void k_kl_centroids_cols75(const float* __restrict__ u, const float* __restrict__ z,
+                                                                         const float* __restrict__ cs, int K, int rows_per_block,
+                                                                         float* __restrict__ w) {
+    __shared__ float zt[kColsQ * 64];
+    const int t = blockIdx.z, d0 = blockIdx.x * 64;
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int kb = blockIdx.y * rows_per_block;
+    const int ke = kb + rows_per_block < K ? kb + rows_per_block : K;
+    if (kb >= ke) return;
+    const float* ft = z + (size_t)t * kColsQ * K;
+    for (int i = threadIdx.x; i < kColsQ * 64; i += 64 * kColsWaves) {
+        const int q = i >> 6, dc = d0 + (i & 63);
+        zt[i] = ft[(size_t)q * K + (dc < K ? dc : K - 1)];
+    }
+    __syncthreads();
+    const int d = d0 + lane;
+    const float* ut = u + (size_t)t * kColsQ * K;
+    const float* zl = zt + lane;
+    for (int kc = kb + wave * kColsChunk; kc < ke; kc += kColsWaves * kColsChunk) {
+        const int k0 = kc + kColsChunk <= K ? kc : K - kColsChunk;   // the last chunk overlaps its predecessor (same values again)
+        float acc[kColsChunk];
+#pragma unroll
+        for (int j = 0; j < kColsChunk; j++) acc[j] = 0.0f;
+        const float* uk = ut + k0;
+#pragma unroll 1
+        for (int g = 0; g < kColsQ / 8; g++) {
+#pragma unroll
+            for (int i = 0; i < 8; i++) {
+                const int q = 8 * g + i;
+                const float zq = zl[q * 64];
+#pragma unroll
+                for (int j = 0; j < kColsChunk; j++) acc[j] = __builtin_fmaf(uk[(size_t)q * K + j], zq, acc[j]);
+            }
+        }
+#pragma unroll
+        for (int q = 8 * (kColsQ / 8); q < kColsQ; q++) {
+            const float zq = zl[q * 64];
+#pragma unroll
+            for (int j = 0; j < kColsChunk; j++) acc[j] = __builtin_fmaf(uk[(size_t)q * K + j], zq, acc[j]);
+        }
+        if (d >= K) continue;
+#pragma unroll
+        for (int j = 0; j < kColsChunk; j++) {
+            const size_t row = (size_t)t * K + k0 + j;
+            const float c = cs[row];
+            w[row * K + d] = (acc[j] / (c < 1.0f ? 1.0f : c)) * (c > 0.0f ? 1.0f : 0.0f);
         }
     }
 }
@@ -3481,8 +3540,18 @@ int tclip_kl_kmeans_run(const tclip_problem* pp, const float* x_q, float* u, flo
     for (int it = 0; it < p.iters; it++) {
         hipLaunchKernelGGL(k_cluster_sizes, dim3((TK + 255) / 256), dim3(256), 0, st, (const float*)u, T, Q, K, 1, cs,
                            live, (float*)nullptr, (int32_t*)nullptr);
-        hipLaunchKernelGGL(k_kl_centroids, dim3((K + 63) / 64, (K + kMstatsRows - 1) / kMstatsRows, T), dim3(64), 0, st,
-                           (const float*)u, x_q, (const float*)cs, Q, K, w);
+        if (Q == kColsQ && K >= kColsChunk && g_mstats_cols != 0) {
+            const int dtiles = (K + 63) / 64;
+            int splits = (int)((8192 + (long)T * dtiles - 1) / ((long)T * dtiles));
+            if (splits > K / (kColsWaves * kColsChunk)) splits = K / (kColsWaves * kColsChunk);
+            if (splits < 1) splits = 1;
+            const int rows_per_block = ((K + splits - 1) / splits + kColsChunk - 1) / kColsChunk * kColsChunk;
+            hipLaunchKernelGGL(k_kl_centroids_cols75, dim3(dtiles, (K + rows_per_block - 1) / rows_per_block, T), dim3(64 * kColsWaves), 0,
+                               st, (const float*)u, x_q, (const float*)cs, K, rows_per_block, w);
+        } else {
+            hipLaunchKernelGGL(k_kl_centroids, dim3((K + 63) / 64, (K + kMstatsRows - 1) / kMstatsRows, T), dim3(64), 0, st,
+                               (const float*)u, x_q, (const float*)cs, Q, K, w);
+        }
         if (g_kmeans_tile != 0 && K >= 32 && K <= 511 && kmeans_tile_lds_raised((const void*)k_kl_divergences_tile)) {
             const int stride = K | 1;
             hipLaunchKernelGGL(k_kl_divergences_tile, dim3((K + kKmeansTile - 1) / kKmeansTile, T), dim3(kKmeansTileThreads),
