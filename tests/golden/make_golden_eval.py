@@ -70,12 +70,14 @@ def main():
     torch.set_num_threads(min(8, os.cpu_count() or 1))
     seed = 2020
     only = set(sys.argv[1:])
-    cases = [("zs", False, None), ("zs", True, None), ("fs", False, None),
+    cases = [("zs", False, None), ("zs", True, None), ("fs", False, None), ("fs", True, None),
              ("zs", False, "HARD_KMEANS"), ("zs", False, "EM_GAUSSIAN"), ("zs", False, "EM_GAUSSIAN_COV"), ("zs", False, "SOFT_KMEANS"), ("zs", False, "KL_KMEANS"), ("zs", False, "CLIP"), ("fs", False, "PADDLE"), ("fs", False, "BDCSPN"), ("fs", False, "ALPHA_TIM"), ("fs", False, "LAPLACIAN_SHOT")]
     for kind, hard, other in cases:
         K = 10
         method = other or ("HARD_EM_DIRICHLET" if hard else "EM_DIRICHLET")
-        if only and method not in only:
+        if only and method not in only and f"{kind}:{method}" not in only:
+            continue
+        if only and method in only and any(":" in o for o in only) and f"{kind}:{method}" not in only:
             continue
         args = Args(iter=10 if (hard or other in ("HARD_KMEANS", "KL_KMEANS")) else 20, iter_mm=1000, num_classes_test=K, n_class=K,
                     n_query=75, k_eff=5, T=30, use_softmax_feature=True, graph_matching=True, shots=2, number_tasks=20,

@@ -248,7 +248,7 @@ def test_bench_scale_call_equals_its_batches_run_alone():
         assert torch.equal(full.criterions[b], single.criterions[0])
 
 
-@pytest.mark.parametrize("name", ["eval_zs_soft_K10", "eval_zs_hard_K10", "eval_fs_soft_K10", "eval_zs_soft_kmeans_K10",
+@pytest.mark.parametrize("name", ["eval_zs_soft_K10", "eval_zs_hard_K10", "eval_fs_soft_K10", "eval_fs_hard_K10", "eval_zs_soft_kmeans_K10",
                                   "eval_zs_hard_kmeans_K10", "eval_zs_em_gaussian_K10", "eval_zs_em_gaussian_cov_K10", "eval_zs_kl_kmeans_K10", "eval_zs_clip_K10",
                                   "eval_fs_paddle_K10", "eval_fs_bdcspn_K10", "eval_fs_alpha_tim_K10", "eval_fs_laplacian_shot_K10"])
 def test_task_batch_loop_matches_reference(name):
