@@ -2692,11 +2692,14 @@ static void launch_kmeans_logits(int T, hipStream_t st, const float* w, const fl
 // Same operations in the same order: products u f added in query order, a0 dumped into a1 after every 16 queries
 // (dsum_cascade with n = 75: four dumps, eleven leftovers), a0 + a1 + a2 + a3 with a2 = a3 = +0 (the zero additions
 // decide the sign of a zero sum).  Rows of the cascade region only, as k_mstats_rows.
+// kCov: EM_GAUSSIAN_COV's inverse variances, y = cs / max(sum_q (wc - f)^2 u, eps), as k_mstats_rows<true>.
 constexpr int kColsQ = 75, kColsChunk = 8, kColsWaves = 4;
+template <bool kCov>
 __global__ __launch_bounds__(64 * kColsWaves) void k_mstats_cols75(const float* __restrict__ u, const float* __restrict__ f,
                                                                    const float* __restrict__ cs, const uint8_t* __restrict__ live,
                                                                    const float* __restrict__ sup, const float* __restrict__ cnt, int K,
-                                                                   int k_rows, int rows_per_block, float* __restrict__ y, int paddle) {
+                                                                   int k_rows, int rows_per_block, float* __restrict__ y, int paddle,
+                                                                   const float* __restrict__ wc) {
     __shared__ float zt[kColsQ * 64];
     const int t = blockIdx.z, d0 = blockIdx.x * 64;
     const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -2726,6 +2729,16 @@ __global__ __launch_bounds__(64 * kColsWaves) void k_mstats_cols75(const float* 
         float a0[kColsChunk], a1[kColsChunk];
 #pragma unroll
         for (int j = 0; j < kColsChunk; j++) a0[j] = a1[j] = 0.0f;
+        float wcv[kColsChunk];
+#pragma unroll
+        for (int j = 0; j < kColsChunk; j++) wcv[j] = kCov ? wc[((size_t)t * K + k0 + j) * K + (d < K ? d : K - 1)] : 0.0f;
+        auto term = [&](int j, float uv, float fv) {
+            if (kCov) {
+                const float df = wcv[j] - fv;
+                return (df * df) * uv;
+            }
+            return uv * fv;
+        };
         const float* uk = ut + k0;                                  // indexed, not walked: a pointer that moves through the loop
                                                                     // turned these wave-uniform loads into per-lane ones
 #pragma unroll 1
@@ -2735,7 +2748,7 @@ __global__ __launch_bounds__(64 * kColsWaves) void k_mstats_cols75(const float* 
                 const int q = 8 * g + i;
                 const float zq = zl[q * 64];
 #pragma unroll
-                for (int j = 0; j < kColsChunk; j++) a0[j] += uk[(size_t)q * K + j] * zq;
+                for (int j = 0; j < kColsChunk; j++) a0[j] += term(j, uk[(size_t)q * K + j], zq);
             }
             if (g & 1) {
 #pragma unroll
@@ -2746,7 +2759,7 @@ __global__ __launch_bounds__(64 * kColsWaves) void k_mstats_cols75(const float* 
         for (int q = 8 * (kColsQ / 8); q < kColsQ; q++) {          // the last three
             const float zq = zl[q * 64];
 #pragma unroll
-            for (int j = 0; j < kColsChunk; j++) a0[j] += uk[(size_t)q * K + j] * zq;
+            for (int j = 0; j < kColsChunk; j++) a0[j] += term(j, uk[(size_t)q * K + j], zq);
         }
         if (d >= K) continue;
 #pragma unroll
@@ -2758,7 +2771,9 @@ __global__ __launch_bounds__(64 * kColsWaves) void k_mstats_cols75(const float* 
             s += 0.0f;                                  // a2, a3 of the cascade: never filled with 75 terms, but added
             s += 0.0f;
             const float c = cs[row];
-            if (paddle == 2) {
+            if (kCov) {
+                y[row * K + d] = c / (s < kEpsF ? kEpsF : s);
+            } else if (paddle == 2) {
                 y[row * K + d] = s / c;
             } else if (sup && paddle) {
                 y[row * K + d] = (s + sup[row * K + d]) / (c + cnt[row]);
@@ -2832,7 +2847,7 @@ static void launch_mstats_mode(hipStream_t st, const float* u, const float* f, c
     const long ncols = (long)K * K;
     const int full_rows = ncols >= 8 ? (int)(((ncols / 32) * 32) / K) : 0;      // rows 0 .. full_rows-1 are all-cascade
     int groups = full_rows / kMstatsRows;
-    if (!kCov && Q == kColsQ && full_rows >= kColsChunk && g_mstats_cols != 0) {
+    if (Q == kColsQ && full_rows >= kColsChunk && g_mstats_cols != 0) {
         // the column kernel takes every row of the cascade region; enough blocks to fill the machine, at least 32 rows each
         const int dtiles = (K + 63) / 64;
         int splits = (int)((8192 + (long)T * dtiles - 1) / ((long)T * dtiles));
@@ -2840,8 +2855,8 @@ static void launch_mstats_mode(hipStream_t st, const float* u, const float* f, c
         if (splits < 1) splits = 1;
         int rows_per_block = ((full_rows + splits - 1) / splits + kColsChunk - 1) / kColsChunk * kColsChunk;
         splits = (full_rows + rows_per_block - 1) / rows_per_block;
-        hipLaunchKernelGGL(k_mstats_cols75, dim3(dtiles, splits, T), dim3(64 * kColsWaves), 0, st, u, f, cs, live, sup, cnt, K, full_rows,
-                           rows_per_block, y, paddle);
+        hipLaunchKernelGGL(k_mstats_cols75<kCov>, dim3(dtiles, splits, T), dim3(64 * kColsWaves), 0, st, u, f, cs, live, sup, cnt, K, full_rows,
+                           rows_per_block, y, paddle, wc);
         groups = full_rows / kMstatsRows;
         const int k_first = full_rows;
         if (k_first < K)
