@@ -7,12 +7,14 @@ import subprocess
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 FLAGS = ["-O2", "-ffp-contract=off", "-mfma", "-fopenmp", "-shared", "-fPIC"]
-HEADER = os.path.join(HERE, "..", "transductive-clip_amd", "csrc", "tclip_math.h")
+CSRC = os.path.join(HERE, "..", "transductive-clip_amd", "csrc")
+HEADERS = [os.path.join(CSRC, h) for h in ("tclip_math.h", "tclip_selftest_inputs.h", "tclip_rsqrt14_table.h", "tclip_rsqrt14_table_dev.h",
+                                             "tclip_rcp14_log_table.h")]
 
 
 def _build(src, out):
     src, out = os.path.join(HERE, src), os.path.join(HERE, out)
-    if os.path.exists(out) and all(os.path.getmtime(d) <= os.path.getmtime(out) for d in (src, HEADER)):
+    if os.path.exists(out) and all(os.path.getmtime(d) <= os.path.getmtime(out) for d in [src] + HEADERS):
         return out
     subprocess.check_call(["g++"] + FLAGS + ["-o", out, src, "-lm"])
     return out

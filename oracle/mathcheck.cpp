@@ -5,6 +5,7 @@
 #include <math.h>
 #include "../transductive-clip_amd/csrc/tclip_math.h"
 #include "../transductive-clip_amd/csrc/tclip_selftest_inputs.h"
+#include "../transductive-clip_amd/csrc/tclip_rsqrt14_table_dev.h"
 extern "C" {
 #define MC_MAP(name, expr) \
     void name(const float* x, float* y, long n) { for (long i = 0; i < n; i++) { const float v = x[i]; y[i] = (expr); } }
@@ -74,6 +75,9 @@ void mc_rec_closed_form(unsigned long long* out) {
             const float whole = tclip::digamma_pos_f32(x1, tclip::kLogTab);
             const float pieces = tclip::digamma_after_rec(xc, tclip::digamma_rec_acc(x1), tclip::kLogTab);
             if (tclip::f32_bits(whole) != tclip::f32_bits(pieces)) bad_psi++;
+            // the dense passes' lean tails (no `x < 1e17` / `x == 1` branches; no partial sum from 10 on)
+            if (tclip::f32_bits(whole) != tclip::f32_bits(tclip::digamma_after_rec_ge10<false>(xc, tclip::digamma_rec_acc(x1), tclip::kLogTab))) bad_psi++;
+            if (x1 >= 10.0f && tclip::f32_bits(whole) != tclip::f32_bits(tclip::digamma_after_rec_ge10<true>(x1, 0.0f, tclip::kLogTab))) bad_psi++;
             if (x1 > 7.0f) {                          // the no-shift form where it is sure (mc_lgamma_gt7_f64_form sweeps the whole domain)
                 bool s1;
                 const float g1 = tclip::lgamma_sleef_gt7_f64<false>(x1, s1);
@@ -104,6 +108,38 @@ void mc_lgamma_gt7_f64_form(unsigned int lo_bits, unsigned int hi_bits, unsigned
         }
     }
     out[0] = bad; out[1] = unsure; out[2] = seen; out[3] = need;
+}
+// torch.sqrt as the MM kernels evaluate it (tclip_device.h: rsqrt14_entry / rsqrt14_from_entry / sqrt_torch_inrange_dev, restated
+// here on the same derived table, whose estimate is the table value also at the exact powers of 4) against sqrt_torch_inrange_f32 on
+// VRSQRT14PS's own values: every float of [1, 4) - every entry, both parities - at exponents 0, -60, +60, -100 and +98, and
+// every power of two of the range.  out: {differences, arguments visited, powers of 4 among them}
+static const uint32_t kMcRsqrt14DevTab[65536] = {TCLIP_RSQRT14_DEV_TABLE_VALUES};
+static float mc_sqrt_dev_form(float x) {
+    const uint32_t b = tclip::f32_bits(x);
+    const uint32_t t = kMcRsqrt14DevTab[(b >> 8) & 0xffffu];
+    const float y = tclip::bits_f32(t - (((b + 0x00800000u) >> 1) & 0x7f800000u));
+    const float s = x * y;
+    return __builtin_fmaf(__builtin_fmaf(-s, s, x), 0.5f * y, s);
+}
+void mc_sqrt_without_pow4(unsigned long long* out) {
+    unsigned long long bad = 0, seen = 0, pow4 = 0;
+    const float scales[5] = {1.0f, 0x1p-60f, 0x1p60f, 0x1p-100f, 0x1p98f};
+    for (uint32_t m = 0; m < (1u << 24); m++) {
+        const float x1 = tclip::bits_f32(0x3f800000u + m);
+        for (int k = 0; k < 5; k++) {
+            const float x = x1 * scales[k];
+            bad += tclip::f32_bits(mc_sqrt_dev_form(x)) != tclip::f32_bits(tclip::sqrt_torch_inrange_f32(x));
+            seen++;
+        }
+        pow4 += m == 0;
+    }
+    for (int e = -100; e <= 100; e++) {
+        const float x = tclip::bits_f32((uint32_t)(127 + e) << 23);
+        bad += tclip::f32_bits(mc_sqrt_dev_form(x)) != tclip::f32_bits(tclip::sqrt_torch_inrange_f32(x));
+        seen++;
+        pow4 += (e & 1) == 0;
+    }
+    out[0] = bad; out[1] = seen; out[2] = pow4;
 }
 // checksums of the routines over the self-test's argument streams (see tclip_selftest_inputs.h)
 void mc_checksums(unsigned long long* out) {

@@ -3,7 +3,10 @@
 
 hipcc cross-compiles without a GPU.  -ffp-contract=off is part of the numerics contract: the
 kernels reproduce the reference's separately rounded fp32 operations and spell every fused
-multiply-add they want explicitly (csrc/tclip_math.h)."""
+multiply-add they want explicitly (csrc/tclip_math.h).  -fno-slp-vectorize: the kernels spell the packed fp32 operations they
+want themselves (csrc/tclip_pk.h); what the SLP vectoriser packed on its own in the MM kernels cost more in register moves and
+explicit negations than the packed instruction saved (gfx950 issues one v_pk_*_f32 in the time of two scalar ones), and its
+packed double-float code spilled."""
 import os
 import subprocess
 import sys
@@ -12,7 +15,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 OUT = os.path.join(HERE, "tclip_amd", "libtclip.so")
 SOURCES = ["tclip_kernels.hip", "tclip_host.cpp"]
-HEADERS = ["tclip_math.h", "tclip_device.h", "tclip_pk.h", "tclip_tim.inc", "tclip_lshot.inc", "tclip_selftest_inputs.h", "tclip_rsqrt14_table.h", "tclip_rcp14_log_table.h", os.path.join("..", "..", "include", "tclip.h")]
+HEADERS = ["tclip_math.h", "tclip_device.h", "tclip_pk.h", "tclip_tim.inc", "tclip_lshot.inc", "tclip_selftest_inputs.h", "tclip_rsqrt14_table.h", "tclip_rsqrt14_table_dev.h", "tclip_rcp14_log_table.h", os.path.join("..", "..", "include", "tclip.h")]
 
 
 def hipcc():
@@ -33,7 +36,7 @@ def up_to_date():
 def build(force=False, verbose=False):
     if not force and up_to_date():
         return OUT
-    cmd = [hipcc(), "--offload-arch=gfx950", "-O3", "-ffp-contract=off", "-fPIC", "-shared", "-pthread", "-std=c++17",
+    cmd = [hipcc(), "--offload-arch=gfx950", "-O3", "-ffp-contract=off", "-fno-slp-vectorize", "-fPIC", "-shared", "-pthread", "-std=c++17",
            "-Wall", "-Wno-unused-function", "-o", OUT] + [os.path.join(CSRC, s) for s in SOURCES]
     if verbose:
         print(" ".join(cmd), flush=True)

@@ -19,6 +19,7 @@
 #include <hip/hip_runtime.h>
 
 #include "tclip_math.h"
+#include "tclip_rsqrt14_table_dev.h"
 
 namespace tclip {
 
@@ -310,6 +311,32 @@ __device__ float dsum_inner_serial(int n, F get) {
     return fin;
 }
 
+// The estimate torch.sqrt's Heron step starts from (sqrt_torch_inrange_f32: y = VRSQRT14PS(x), s = x y,
+// root = fma(fma(-s, s, x), y / 2, s)), from x's bits b (positive normal) and the entry of the derived table
+// (tclip_rsqrt14_table_dev.h: indexed by bit 23 and the top 15 mantissa bits of b as they stand, the estimate's mantissa
+// already in place under the exponent of 2^63).  x = m 4^k, m in [1, 4); with E the biased exponent k = ((E + 1) >> 1) - 64
+// whatever E's parity, so the scaling is one subtraction of bits 24..31 of b + 2^23, moved down one place: two instructions
+// for the index and three here, where the 16-bit table took three and seven (integer and select instructions issue at 16
+// lanes per clock on gfx950, fp32 arithmetic at 32: the ten were a tenth of an update's issue time).
+// NOT VRSQRT14PS at the exact powers of 4: the instruction returns 2^-k there, this returns the table's value for the
+// mantissas just above (2^-k (1 - 3 2^-17)).  The square root does not see the difference: with y = 2^-k (1 + e) the product
+// s = 2^k (1 + e) is exact, fma(-s, s, x) = -4^k (2 e + e^2) to 2^-24, and the result is RN(2^k (1 - 3 e^2 / 2 + ..)) = 2^k for
+// every |e| <= 2^-14 - what the exact estimate gives.  oracle/mathcheck.cpp (mc_sqrt_without_pow4) and k_selftest check
+// the whole root, on every power of two of the range and on every float of [1, 4).
+static __device__ const uint32_t kRsqrt14DevTab[65536] = {TCLIP_RSQRT14_DEV_TABLE_VALUES};
+
+__device__ __forceinline__ uint32_t rsqrt14_entry(uint32_t b) { return kRsqrt14DevTab[(b >> 8) & 0xffffu]; }
+__device__ __forceinline__ float rsqrt14_from_entry(uint32_t b, uint32_t t) {
+    return bits_f32(t - (((b + 0x00800000u) >> 1) & 0x7f800000u));
+}
+
+__device__ __forceinline__ float sqrt_torch_inrange_dev(float x) {     // sqrt_torch_inrange_f32 on the derived table
+    const uint32_t b = f32_bits(x);
+    const float y = rsqrt14_from_entry(b, rsqrt14_entry(b));
+    const float s = x * y;
+    return __builtin_fmaf(__builtin_fmaf(-s, s, x), 0.5f * y, s);
+}
+
 // One majorize-minimize update of a single Dirichlet parameter (em_dirichlet.py:153-167), given
 // psi1 = digamma(a+1) and lg1 = lgamma(a+1): the operation order and the roundings (no
 // contraction) of the torch CPU ops.  Branch-free; valid for mm_fast_domain(a), finite y, psi_s.
@@ -320,7 +347,7 @@ __device__ __forceinline__ float mm_update_algebra(float a, float y, float psi_s
     float b = (psi1 - psi_s) - curv * a;
     b = b - y;
     const float delta = b * b + 4.0f * curv;
-    const float nume = -b + sqrt_torch_inrange_f32(delta), deno = 2.0f * curv;
+    const float nume = -b + sqrt_torch_inrange_dev(delta), deno = 2.0f * curv;
     // curvature exactly 0 (total cancellation in t): IEEE x/0 = +-inf or nan, as the reference gets
     return deno == 0.0f ? nume * __builtin_inff() : div_rn_inrange_f32(nume, deno);
 }

@@ -992,7 +992,8 @@ __device__ __forceinline__ float lgamma_gt7_dense(float v) {
 }
 
 // phase C of the split iteration: entry `slot` of the wavefront's planes holds lgamma(a+1) and digamma(a+1)
-template <int E, int G>
+// kTiny: some parameter of the wavefront's rows may be 1e-11 or less (see pk_mm_update_stage1_core)
+template <int E, int G, bool kTiny>
 __device__ __forceinline__ void split_apply_updates(float (&beta)[E], const RowY<E, G, TCLIP_SPLIT_Y_REGS_MAX_E>& yv, int K, int lane, float psi_s,
                                                     const float* my0, const float* my1, const uint32_t (&slot)[(E + 1) / 2],
                                                     bool measure, double& num, double& den) {
@@ -1022,8 +1023,7 @@ __device__ __forceinline__ void split_apply_updates(float (&beta)[E], const RowY
         const int e = 2 * p;
         const f2 a{beta[e], beta[e + 1]};
         const int i0 = (int)(slot[p] & 0xffffu), i1 = (int)(slot[p] >> 16);
-        const f2 lg{my0[i0], my0[i1]}, psi1{my1[i0], my1[i1]};
-        const PkUpdateStage st = pk_mm_update_stage1_given(a, f2{yv.get(e), yv.get(e + 1)}, pk(psi_s), psi1, lg);
+        const PkUpdateStage st = pk_mm_update_stage1_given<kTiny>(a, f2{yv.get(e), yv.get(e + 1)}, psi_s, my1[i0], my1[i1], my0[i0], my0[i1]);
         if (p > 0) finish(p - 1, pending);
         pending = st;
     }
@@ -1091,20 +1091,31 @@ __device__ __forceinline__ void mm_iterate_wave_split(float (&beta)[E], const Ro
     // the 64-lane layout); their slots are masked out of the queues, all other registers are queued whole.
     // (Lane groups without a row hold zeros and travel as class A; they only occur in the last block of a list.)
     constexpr int kFirstRagged = E > 4 ? E - 4 : 0;
+    // The same sweep notes whether any parameter is 1e-11 or less (the curvature's constant branch, em_dirichlet.py:155): phase C
+    // of a wavefront without one runs without that compare and select.  A running minimum over the parameters' bit patterns
+    // as signed integers (the order of the non-negative floats; -0 sorts below everything and counts as small), three values
+    // per instruction and no lane mask to keep - sixteen ballots lived in scalar registers the kernel does not have and went
+    // through v_writelane / v_readlane.  Slots beyond the row hold 0 and do not take part.
     int nA = 0, nC = 0, nV = kFirstRagged * 64;
+    int32_t smallest = 0x7f800000;
 #pragma unroll
     for (int e = 0; e < E; e++) {
         const float x1 = beta[e] + 1.0f;
         unsigned long long mA = __builtin_amdgcn_ballot_w64(x1 < 2.3f), mC = __builtin_amdgcn_ballot_w64(x1 >= 10.0f);
+        int32_t bits = (int32_t)f32_bits(beta[e]);
         if (e >= kFirstRagged) {
-            const unsigned long long mv = __builtin_amdgcn_ballot_w64(elem_of<E, G>(e, lane) < K);
+            const bool in_row = elem_of<E, G>(e, lane) < K;
+            const unsigned long long mv = __builtin_amdgcn_ballot_w64(in_row);
             mA &= mv;
             mC &= mv;
             nV += __popcll(mv);
+            bits = in_row ? bits : 0x7f800000;
         }
+        smallest = bits < smallest ? bits : smallest;
         nA += __popcll(mA);
         nC += __popcll(mC);
     }
+    const bool tiny = __builtin_amdgcn_ballot_w64(smallest <= (int32_t)0x2d2febffu) != 0ull;      // 0x2d2febff = 1e-11f
     const int nB = nV - nA - nC;                                    // NaN compares false twice: class B, in both sweeps
     // second sweep: every element's argument to its place in [A | B | C]; the place is kept (16 bits) for the pick-up.
     // The compares are repeated on purpose (the asm keeps the compiler from holding 2 E masks in scalar registers).
@@ -1179,7 +1190,7 @@ __device__ __forceinline__ void mm_iterate_wave_split(float (&beta)[E], const Ro
         const float m = below10_f32(xr);
         acc = __builtin_fmaf(-m, rcp_rn_f32(xr), acc);
         xr = xr + m;
-        const float psi = digamma_after_rec(xr, acc, tab);
+        const float psi = digamma_after_rec_ge10<false>(xr, acc, tab);
         bool sure;
         float lg = lgamma_sleef_1_23_f64(x, sure);
         if (__builtin_expect(__builtin_amdgcn_ballot_w64(!sure) != 0ull, 0)) lg = sure ? lg : lgamma_sleef_05_23(x);
@@ -1196,7 +1207,7 @@ __device__ __forceinline__ void mm_iterate_wave_split(float (&beta)[E], const Ro
             acc = __builtin_fmaf(-m, rcp_rn_f32(xr), acc);
             xr += m;
         }
-        const float psi = digamma_after_rec(xr, acc, tab);
+        const float psi = digamma_after_rec_ge10<false>(xr, acc, tab);
         const float lg = lgamma_big_dense(x);
         if (ok) { my0[i] = lg; my1[i] = psi; }
     };
@@ -1215,13 +1226,14 @@ __device__ __forceinline__ void mm_iterate_wave_split(float (&beta)[E], const Ro
         const int i = nA + nB + j + lane64;
         const bool ok = j + lane64 < nC;
         const float x = ok ? my0[i] : 16.0f;
-        const float psi = digamma_after_rec(x, 0.0f, tab);
+        const float psi = digamma_after_rec_ge10<true>(x, 0.0f, tab);
         const float lg = lgamma_gt7_dense(x);
         if (ok) { my0[i] = lg; my1[i] = psi; }
     }
     // phase C
     wave_lds_handoff();
-    split_apply_updates<E, G>(beta, yv, K, lane, psi_s, my0, my1, slot, measure, num, den);
+    if (__builtin_expect(tiny, 0)) split_apply_updates<E, G, true>(beta, yv, K, lane, psi_s, my0, my1, slot, measure, num, den);
+    else split_apply_updates<E, G, false>(beta, yv, K, lane, psi_s, my0, my1, slot, measure, num, den);
     wave_lds_handoff();
 }
 
@@ -2357,6 +2369,17 @@ __global__ void k_selftest(unsigned long long* out) {
         b4 += differ1;
         if (differ0) { out[14] = f32_bits(a); out[15] = f32_bits(y); out[16] = f32_bits(ps); out[17] = f32_bits(up.x); out[18] = f32_bits(ug); }
         if (differ1) { out[14] = f32_bits(a2); out[15] = f32_bits(y); out[16] = f32_bits(ps); out[17] = f32_bits(up.y); out[18] = f32_bits(ug2); }
+        // the split kernel's form: digamma and lgamma of a+1 handed over per component; without the small-parameter select
+        // where it may be dropped
+        float p2, l2;
+        digamma_lgamma_xp1(a2, tab, p2, l2);
+        const f2 yy{y, y};
+        const f2 us = pk_mm_update_stage2(pk_mm_update_stage1_given<true>(av, yy, ps, p, p2, l, l2));
+        b4 += !(us.x == ug || (us.x != us.x && ug != ug)) || !(us.y == ug2 || (us.y != us.y && ug2 != ug2));
+        if (a > 1e-11f && a2 > 1e-11f) {
+            const f2 un = pk_mm_update_stage2(pk_mm_update_stage1_given<false>(av, yy, ps, p, p2, l, l2));
+            b4 += f32_bits(un.x) != f32_bits(us.x) || f32_bits(un.y) != f32_bits(us.y);
+        }
     }
     // (3, continued) the fp64 form of lgamma on every float of [1, 2.3): where it is sure it must agree
     for (uint32_t b = f32_bits(1.0f) + tid; b < f32_bits(2.3f); b += nth) {
@@ -2374,7 +2397,7 @@ __global__ void k_selftest(unsigned long long* out) {
         if (x > 7.0f) {
             bool sure7;
             const float fast7 = lgamma_sleef_gt7_f64<true>(x, sure7);
-            b3 += f32_bits(fast7) != f32_bits(fast) || sure7 != sure;
+            b3 += sure7 && f32_bits(fast7) != f32_bits(lgamma_sleef_ge23<true>(x));
         }
     }
     // (2, continued) digamma in the pieces the class-split kernel uses, on every float of [1, 16): the closed form of where
@@ -2384,6 +2407,8 @@ __global__ void k_selftest(unsigned long long* out) {
         const float xc = digamma_rec_x(x1), acc = digamma_rec_acc(x1);
         b2 += f32_bits(xc) != f32_bits(digamma_rec_x_loop(x1));
         b2 += f32_bits(digamma_after_rec(xc, acc, tab)) != f32_bits(digamma_pos_f32(x1, tab));
+        b2 += f32_bits(digamma_after_rec_ge10<false>(xc, acc, tab)) != f32_bits(digamma_pos_f32(x1, tab));
+        if (x1 >= 10.0f) b2 += f32_bits(digamma_after_rec_ge10<true>(x1, 0.0f, tab)) != f32_bits(digamma_pos_f32(x1, tab));
         const f2 xp{x1, bits_f32(b ^ 0x00400000u)};           // a second argument from the other half of the binade
         const f2 xcp = pk_digamma_rec_x(xp), accp = pk_digamma_rec_acc(xp), psip = pk_digamma_after_rec(xcp, accp, tab);
         b2 += f32_bits(xcp.x) != f32_bits(xc) || f32_bits(accp.x) != f32_bits(acc);
@@ -2393,6 +2418,20 @@ __global__ void k_selftest(unsigned long long* out) {
         }
         if (x1 >= 2.3f) b2 += f32_bits(digamma_rec_acc_ge23(x1)) != f32_bits(acc);
         b2 += f32_bits(psip.x) != f32_bits(digamma_pos_f32(xp.x, tab)) || f32_bits(psip.y) != f32_bits(digamma_pos_f32(xp.y, tab));
+    }
+    // (4, continued) torch.sqrt on the derived table (whose estimate is not VRSQRT14PS's at the exact powers of 4) against the
+    // restatement on the instruction's own values: every float of [1, 4) - all table entries, both parities - at three
+    // scales, and every power of two of the range
+    for (uint32_t m = tid; m < (1u << 24); m += nth) {
+        const float x = bits_f32(0x3f800000u + m);
+        const f2 r = pk_sqrt_torch_inrange(f2{x, x * 0x1p-60f});
+        b4 += f32_bits(r.x) != f32_bits(sqrt_torch_inrange_f32(x)) || f32_bits(r.y) != f32_bits(sqrt_torch_inrange_f32(x * 0x1p-60f));
+        b4 += f32_bits(sqrt_torch_inrange_dev(x * 0x1p61f)) != f32_bits(sqrt_torch_inrange_f32(x * 0x1p61f));
+    }
+    for (int e = -100 + (int)tid; e <= 100; e += (int)nth) {
+        const float x = bits_f32((uint32_t)(127 + e) << 23);
+        b4 += f32_bits(sqrt_torch_inrange_dev(x)) != f32_bits(sqrt_torch_inrange_f32(x));
+        b4 += f32_bits(pk_sqrt_torch_inrange(pk(x)).y) != f32_bits(sqrt_torch_inrange_f32(x));
     }
     atomicAdd(&out[0], b0); atomicAdd(&out[1], b1); atomicAdd(&out[2], b2);
     atomicAdd(&out[3], b3); atomicAdd(&out[4], b4); atomicAdd(&out[5], b5);

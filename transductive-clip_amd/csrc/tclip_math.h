@@ -514,6 +514,18 @@ TCLIP_HD double log1p_small_f64(double w) {
     p = __builtin_fma(p, w, 1.0);
     return p * w;
 }
+// The same with everything from the cubic term on in fp32: w^3 (1/3 - w/4 + w^2/5 - w^3/6) <= 6e-7, so four fp32 roundings
+// leave < 2e-13 absolute - 200 of the 8192 sub-float positions the `sure` window allows at lgamma(7) = 6.6, fewer beyond -
+// and w - w^2/2 keeps its fp64 form.  Three fp64 operations and a conversion where the Horner form took six, and none of
+// its four constants, which are not inline constants of the fp64 instructions (the compiler rebuilt them in registers
+// for every argument).  wf = RN32(w).
+TCLIP_HD double log1p_small_split(double w, float wf) {
+    float q = __builtin_fmaf(wf, -1.0f / 6.0f, 1.0f / 5.0f);
+    q = __builtin_fmaf(q, wf, -1.0f / 4.0f);
+    q = __builtin_fmaf(q, wf, 1.0f / 3.0f);
+    const float tail = ((wf * wf) * wf) * q;
+    return __builtin_fma(w * w, -0.5, w) + (double)tail;
+}
 TCLIP_HD uint32_t f64_distance_from_f32_midpoint(double v) {
     const uint32_t below = (uint32_t)f64_bits(v) & 0x1fffffffu;
     return below >= 0x10000000u ? below - 0x10000000u : 0x10000000u - below;
@@ -545,7 +557,7 @@ TCLIP_HD float lgamma_sleef_ge23_f64_core(float a, double& pd, double& v) {
     double c = __builtin_fma(xd - 0.5, logk2f_f64<kFast>(xh, xd), -xd) + kHalfLog2PiDf;
     // corr = 1 + u t (u t is exact in fp64), divided by the shift product
     if (kGt7) {                                                    // prod = 1: the quotient is corr itself
-        v = c + log1p_small_f64((double)u * (double)t);
+        v = c + log1p_small_split((double)u * (double)t, u * t);
         return (float)v;
     }
     const float ch = u * t + 1.0f;                                 // hi word of corr
@@ -764,6 +776,35 @@ TCLIP_HD float digamma_rec_x(float x1) {                 // 1 <= x1 <= 2^41
 TCLIP_HD float digamma_after_rec(float x, float acc, const LogTabEntry* tab) {
     const float series = digamma_series<true>(x, acc, tab);
     return (x == 10.0f) ? acc + 2.25175258906672110764f : series;
+}
+// The same where the recurrence has run or was not needed, 10 <= x <= 2^41 (every caller in the split kernel's dense passes):
+// digamma_series without its `x < 1e17` branch and logf without its `x == 1` branch - a compare, a select-like branch and
+// their bookkeeping per argument, which issue at half an fma's rate.  kNoAcc: acc is +0 (arguments from 10 on take no step) and
+// 0 + logf(x) is logf(x): a positive number.
+template <bool kNoAcc>
+TCLIP_HD float digamma_after_rec_ge10(float x, float acc, const LogTabEntry* tab) {
+    const float z = rcp_ieee<true>(x * x);
+    float p = 8.33333333333333333333E-2f;
+    p = __builtin_fmaf(p, z, -2.10927960927960927961E-2f);
+    p = __builtin_fmaf(p, z, 7.57575757575757575758E-3f);
+    p = __builtin_fmaf(p, z, -4.16666666666666666667E-3f);
+    p = __builtin_fmaf(p, z, 3.96825396825396825397E-3f);
+    p = __builtin_fmaf(p, z, -8.33333333333333333333E-3f);
+    p = __builtin_fmaf(p, z, 8.33333333333333333333E-2f);
+    const float y = z * p;
+    double r, y0;
+    log_reduce_tab(x, tab, r, y0);
+    const double r2 = r * r;
+    double l = __builtin_fma(0x1.5575b0be00b6ap-2, r, -0x1.ffffef20a4123p-2);
+    l = __builtin_fma(-0x1.00ea348b88334p-2, r2, l);
+    l = __builtin_fma(l, r2, y0 + r);
+    const float lg = (float)l;
+    const float series = ((kNoAcc ? lg : acc + lg) - 0.5f * rcp_ieee<true>(x)) - y;
+    const float at10 = kNoAcc ? 2.25175258906672110764f : acc + 2.25175258906672110764f;
+#if defined(__HIP_DEVICE_COMPILE__)
+    if (__builtin_expect(__builtin_amdgcn_ballot_w64(x == 10.0f) == 0ull, 1)) return series;   // wave-uniform: no select
+#endif
+    return (x == 10.0f) ? at10 : series;
 }
 
 TCLIP_HD void digamma_lgamma_xp1(float a, const LogTabEntry* tab, float& psi1, float& lg1) {

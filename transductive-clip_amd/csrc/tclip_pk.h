@@ -11,7 +11,7 @@
 // same fast domain 0 <= a <= 2^40; k_selftest compares the two bit for bit on 2^24 arguments.
 // Device only.
 #pragma once
-#include "tclip_math.h"
+#include "tclip_device.h"
 
 namespace tclip {
 
@@ -36,6 +36,15 @@ __device__ __forceinline__ f2 pk_div_rn(f2 a, f2 b) {
     const f2 q = a * r;
     const f2 rem = pk_fma(-b, q, a);
     return pk_fma(rem, r, q);
+}
+
+// RN(a / b) from nb = -b: the reciprocal takes -nb through its source modifier and both fused steps take nb as it is, so no
+// instruction is spent on a negation (with b in a register the compiler materialised -b with two v_xor per pair)
+__device__ __forceinline__ f2 pk_div_rn_negden(f2 a, f2 nb) {
+    const f2 r0{__builtin_amdgcn_rcpf(-nb.x), __builtin_amdgcn_rcpf(-nb.y)};
+    const f2 r = pk_fma(pk_fma(nb, r0, pk(1.0f)), r0, r0);
+    const f2 q = a * r;
+    return pk_fma(pk_fma(nb, q, a), r, q);
 }
 
 // logf_glibc_tab of two arguments that are not 1.0f (here: >= 10, the recurrence has run), without its x == 1 branch
@@ -221,26 +230,11 @@ __device__ __forceinline__ f2 pk_lgamma_sleef_1_23(f2 x) {
     return r;
 }
 
-// VRSQRT14PS(x) from x's bits b (positive normal) and its table entry t, see rsqrt14_f32: (0.5 | t << 7) * 2^-k with
-// x = m 4^k, m in [1, 4), and 1.0 * 2^-k for the exact powers of 4.  With E the biased exponent, k = ((E + 1) >> 1) - 64
-// whatever E's parity, so the scaling is one subtraction of bits 24..31 of b + 2^23, moved down one place, from a base that
-// carries the 64: eight integer instructions per element where the literal form (exponent, parity, (E - 127 - parity) / 2,
-// a select on mantissa | parity) took eleven.  k_selftest compares it with rsqrt14_f32 through sqrt_torch / the MM update.
-__device__ __forceinline__ float rsqrt14_from_entry(uint32_t b, uint32_t t) {
-    uint32_t yb = 0x5f000000u | (t << 7);
-    yb = (b & 0x00ffffffu) == 0x00800000u ? 0x5f800000u : yb;          // mantissa 0 and E odd (even unbiased exponent): 4^k
-    return bits_f32(yb - (((b + 0x00800000u) >> 1) & 0x7f800000u));
-}
-
 // torch.sqrt, see sqrt_torch_inrange_f32
 // both table look-ups of a pair issued together (one memory latency per pair instead of two in a row)
 __device__ __forceinline__ f2 pk_rsqrt14(f2 x) {
     const uint32_t b0 = f32_bits(x.x), b1 = f32_bits(x.y);
-    const int ue0 = (int)(b0 >> 23) - 127, ue1 = (int)(b1 >> 23) - 127;
-    const int par0 = ue0 & 1, par1 = ue1 & 1;
-    const uint32_t mant0 = b0 & 0x7fffffu, mant1 = b1 & 0x7fffffu;
-    const uint32_t t0 = kRsqrt14Tab[((uint32_t)par0 << 15) | (mant0 >> 8)];
-    const uint32_t t1 = kRsqrt14Tab[((uint32_t)par1 << 15) | (mant1 >> 8)];
+    const uint32_t t0 = rsqrt14_entry(b0), t1 = rsqrt14_entry(b1);
     return f2{rsqrt14_from_entry(b0, t0), rsqrt14_from_entry(b1, t1)};
 }
 
@@ -265,47 +259,37 @@ __device__ __forceinline__ f2 pk_update_quotient(f2 nume, f2 deno) {
     return q;
 }
 
-// One MM update of two parameters (psi_s: digamma of the row sum of each one's row), see mm_update_algebra.
-__device__ __forceinline__ f2 pk_mm_update_algebra(f2 a, f2 y, f2 psi_s, f2 psi1, f2 lg1) {
-    const f2 t = pk_t_of(lg1, psi1 * a);
-    const f2 big = __builtin_elementwise_abs(pk_div_rn(pk(2.0f) * t, a * a));
-    const f2 curv = pk_sel(a > pk(1e-11f), big, pk(1.6449340668482264f));
-    f2 b = (psi1 - psi_s) - curv * a;
-    b = b - y;
-    const f2 delta = pk_fma(pk(4.0f), curv, b * b);
-    const f2 nume = -b + pk_sqrt_torch_inrange(delta), deno = pk(2.0f) * curv;
-    return pk_update_quotient(nume, deno);
-}
-
-// lg1 = lgamma(a+1): the caller supplies the large-argument results (a+1 >= 2.3) it evaluated
-// elsewhere; the polynomial branch is computed here for the rest.
-__device__ __forceinline__ f2 pk_mm_update(f2 a, f2 y, f2 psi_s, f2 lg_big, const LogTabEntry* tab) {
-    const f2 x1 = a + pk(1.0f);
-    const i2 big = x1 >= pk(2.3f);
-    const f2 lg_small = pk_lgamma_sleef_1_23(pk_sel(big, pk(2.0f), x1));
-    const f2 psi1 = pk_digamma_xp1(a, tab);
-    return pk_mm_update_algebra(a, y, psi_s, psi1, pk_sel(big, lg_big, lg_small));
-}
-
-// The same update in two stages, so that a caller can put other work (the next pair's digamma) between the
+// One MM update of two parameters (see mm_update_algebra) in two stages, so that a caller can put other work (the next pair's digamma) between the
 // table look-ups of torch.sqrt's VRSQRT14 emulation and their first use: stage 1 ends by issuing the two loads.
 struct PkUpdateStage {
     f2 b, curv, delta;
     uint32_t t0, t1;            // table entries of delta.x, delta.y (loaded, not yet used)
 };
-// stage 1 from psi1 = digamma(a+1) and lg1 = lgamma(a+1)
-__device__ __forceinline__ PkUpdateStage pk_mm_update_stage1_given(f2 a, f2 y, f2 psi_s, f2 psi1, f2 lg1) {
-    const f2 t = pk_t_of(lg1, psi1 * a);
-    const f2 bigv = __builtin_elementwise_abs(pk_div_rn(pk(2.0f) * t, a * a));
+// stage 1 from t = lgamma-and-digamma term of the curvature (pk_t_of) and d = digamma(a+1) - digamma(row sum), each given per
+// component.  |2 t / a^2| is formed as (|t| + |t|) / a^2 - the same number: the doubling is exact and the quotient's rounding is
+// symmetric in sign - because the scalar add takes |t| through its source modifiers, where the packed pipe has none and the
+// absolute value of the quotient cost a select per component.
+// kTiny = false: the caller knows that every parameter of the wavefront's rows exceeds 1e-11 (the curvature of smaller ones is
+// the constant polygamma(1, 1), em_dirichlet.py:155) and the two compares and selects per pair go too.
+template <bool kTiny>
+__device__ __forceinline__ PkUpdateStage pk_mm_update_stage1_core(f2 a, f2 y, float t0, float t1, f2 d) {
+    const f2 t2{__builtin_fabsf(t0) + __builtin_fabsf(t0), __builtin_fabsf(t1) + __builtin_fabsf(t1)};
+    const f2 bigv = pk_div_rn_negden(t2, -a * a);
     PkUpdateStage st;
-    st.curv = pk_sel(a > pk(1e-11f), bigv, pk(1.6449340668482264f));
-    f2 b = (psi1 - psi_s) - st.curv * a;
-    st.b = b - y;
+    if (kTiny) st.curv = pk_sel(a > pk(1e-11f), bigv, pk(1.6449340668482264f));
+    else st.curv = bigv;
+    st.b = (d - st.curv * a) - y;
     st.delta = pk_fma(pk(4.0f), st.curv, st.b * st.b);           // 4 curv is exact: one rounding, as b b + 4 curv has
-    const uint32_t b0 = f32_bits(st.delta.x), b1 = f32_bits(st.delta.y);
-    st.t0 = kRsqrt14Tab[((((b0 >> 23) - 127u) & 1u) << 15) | ((b0 & 0x7fffffu) >> 8)];
-    st.t1 = kRsqrt14Tab[((((b1 >> 23) - 127u) & 1u) << 15) | ((b1 & 0x7fffffu) >> 8)];
+    st.t0 = rsqrt14_entry(f32_bits(st.delta.x));
+    st.t1 = rsqrt14_entry(f32_bits(st.delta.y));
     return st;
+}
+// stage 1 from digamma(a+1) and lgamma(a+1) of the two parameters, each in a register of its own (the split kernel reads them
+// from its LDS planes: packing them first cost three moves per pair, and a fourth for the row's digamma)
+template <bool kTiny>
+__device__ __forceinline__ PkUpdateStage pk_mm_update_stage1_given(f2 a, f2 y, float psi_s, float psi10, float psi11, float lg10, float lg11) {
+    const float m0 = psi10 * a.x, m1 = psi11 * a.y;
+    return pk_mm_update_stage1_core<kTiny>(a, y, m0 - lg10, m1 - lg11, f2{psi10 - psi_s, psi11 - psi_s});
 }
 __device__ __forceinline__ PkUpdateStage pk_mm_update_stage1(f2 a, f2 y, f2 psi_s, f2 lg_big, const LogTabEntry* tab) {
     const f2 x1 = a + pk(1.0f);
@@ -314,16 +298,7 @@ __device__ __forceinline__ PkUpdateStage pk_mm_update_stage1(f2 a, f2 y, f2 psi_
     const f2 psi1 = pk_digamma_xp1(a, tab);
     const f2 lg1 = pk_sel(big, lg_big, lg_small);
     const f2 t = pk_t_of(lg1, psi1 * a);
-    const f2 bigv = __builtin_elementwise_abs(pk_div_rn(pk(2.0f) * t, a * a));
-    PkUpdateStage st;
-    st.curv = pk_sel(a > pk(1e-11f), bigv, pk(1.6449340668482264f));
-    f2 b = (psi1 - psi_s) - st.curv * a;
-    st.b = b - y;
-    st.delta = pk_fma(pk(4.0f), st.curv, st.b * st.b);           // 4 curv is exact: one rounding, as b b + 4 curv has
-    const uint32_t b0 = f32_bits(st.delta.x), b1 = f32_bits(st.delta.y);
-    st.t0 = kRsqrt14Tab[((((b0 >> 23) - 127u) & 1u) << 15) | ((b0 & 0x7fffffu) >> 8)];
-    st.t1 = kRsqrt14Tab[((((b1 >> 23) - 127u) & 1u) << 15) | ((b1 & 0x7fffffu) >> 8)];
-    return st;
+    return pk_mm_update_stage1_core<true>(a, y, t.x, t.y, psi1 - psi_s);
 }
 __device__ __forceinline__ f2 pk_mm_update_stage2(const PkUpdateStage& st) {
     const f2 yr{rsqrt14_from_entry(f32_bits(st.delta.x), st.t0), rsqrt14_from_entry(f32_bits(st.delta.y), st.t1)};
@@ -331,6 +306,11 @@ __device__ __forceinline__ f2 pk_mm_update_stage2(const PkUpdateStage& st) {
     const f2 root = pk_fma(pk_fma(-s, s, st.delta), pk(0.5f) * yr, s);
     const f2 nume = -st.b + root, deno = pk(2.0f) * st.curv;
     return pk_update_quotient(nume, deno);
+}
+
+// both stages at once (k_selftest): lg_big = lgamma(a+1) for the components with a+1 >= 2.3, evaluated by the caller
+__device__ __forceinline__ f2 pk_mm_update(f2 a, f2 y, f2 psi_s, f2 lg_big, const LogTabEntry* tab) {
+    return pk_mm_update_stage2(pk_mm_update_stage1(a, y, psi_s, lg_big, tab));
 }
 
 }  // namespace tclip
