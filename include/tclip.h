@@ -293,6 +293,12 @@ int tclip_debug_set_rowset_min_rows(int32_t rows);
  * results do not depend on it. */
 int tclip_debug_set_mm_split(int32_t mode);
 
+/* The MM kernels are also compiled with the row length as a constant for the class counts of the reference's datasets that
+ * BASELINE.json runs (1000, 397, 100): same layout and operations as the run-time-K kernel of the row length's bucket.  For
+ * tests: 0 launches the run-time-K kernels for every row length, anything else restores the default.  Process-wide; results
+ * do not depend on it. */
+int tclip_debug_set_fixed_k_kernels(int32_t on);
+
 /* The squared distances of the k-means family (SOFT/HARD_KMEANS, EM_GAUSSIAN, PADDLE, BD-CSPN) and KL_KMEANS's divergences run one
  * lane per class on a 64-centroid tile staged in LDS for rows of 32 .. 511 elements (k_kmeans_logits_tile, k_kl_divergences_tile),
  * 32 lanes per class otherwise; the centroid statistics of 75-query problems stage 64 feature columns per block (k_mstats_cols75).  For

@@ -392,3 +392,45 @@ def test_bench_prints_one_json_line_under_rccl():
     # a launcher whose world size differs from --gpus is refused
     bad = subprocess.run(cmd[:cmd.index("--gpus") + 1] + ["2"] + cmd[cmd.index("--gpus") + 2:], capture_output=True, text=True, timeout=600)
     assert bad.returncode != 0 and "--gpus 2" in (bad.stderr + bad.stdout)
+
+
+def _set_fixed_k(on):
+    from tclip_amd import _capi
+    _capi.check(_capi.lib().tclip_debug_set_fixed_k_kernels(on), "tclip_debug_set_fixed_k_kernels")
+
+
+@pytest.mark.parametrize("K,N,shots,hard,nan", [(1000, 5, 0, False, False), (1000, 3, 1, False, False), (1000, 3, 0, True, True),
+                                                (397, 6, 0, True, False), (397, 4, 2, False, False), (397, 4, 0, False, True),
+                                                (100, 12, 0, False, False), (100, 6, 2, True, False), (100, 9, 0, False, True)])
+def test_fixed_row_length_kernels_are_invisible(K, N, shots, hard, nan):
+    """The MM kernels compiled with the row length as a constant (K = 1000 / 397 / 100, launch_mm) against the run-time-K
+    kernels of the same bucket on the same problems: identical bits - alpha, u, v, predictions, MM counts, criterions - zero-
+    and few-shot, soft and hard, two batches per call (one of which may stop early), and with a NaN feature (the generic
+    per-wavefront path of both kernels).  The profiler's kernel names confirm which kernels ran."""
+    from tclip_amd import engine, synth
+    from test_gpu_round3 import _mm_launch_names
+    B = 2
+    x_q, _ = synth.make_query_tasks(B * N, K, seed=9100 + K + shots, k_eff=(5 if shots else None))
+    if nan:
+        x_q[1, 3, 2] = float("nan")
+    x_s = y_s = None
+    if shots:
+        x_s, y_s = synth.make_support(B * N, K, shots, seed=9200 + K)
+        x_s, y_s = x_s.to(DEV), y_s.squeeze(2).to(DEV)
+    kw = dict(n_batches=B, iters=3, iter_mm=151, lambd=max(1, int(K / 5)) * 75, hard=hard)
+    res, names = {}, {}
+    try:
+        for on in (0, 1):
+            _set_fixed_k(on)
+
+            def run(on=on):
+                res[on] = engine.run_em_dirichlet(x_q.to(DEV), x_s, y_s, **kw)
+            names[on] = _mm_launch_names(run)
+    finally:
+        _set_fixed_k(1)
+    tag = f", {K}>"
+    assert any(tag in n for n in names[1]), names[1]
+    assert not any(tag in n for n in names[0]), names[0]
+    for name in ("alpha", "u", "v", "preds", "mm_iters", "criterions"):
+        a, b = getattr(res[1], name), getattr(res[0], name)
+        assert torch.equal(a, b) or (nan and np.array_equal(a.cpu().numpy(), b.cpu().numpy(), equal_nan=True)), name

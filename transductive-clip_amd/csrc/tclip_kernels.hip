@@ -474,7 +474,7 @@ __device__ __forceinline__ int elem_of(int e, int lane) {
 }
 // registers below this index hold only elements inside the row (wave-uniform)
 template <int E, int G>
-__device__ __forceinline__ int full_registers(int K) {
+__host__ __device__ constexpr int full_registers(int K) {
     if constexpr (G == 64) return K > E * 32 ? (K - E * 32) / 32 : 0;
     else return K / G;
 }
@@ -594,18 +594,35 @@ __device__ __forceinline__ void mm_apply_updates(float (&beta)[E], const RowY<E,
 // Registers of an MM kernel instantiation that lie inside the row - and inside the 4-way interleaved part of torch's row
 // sum - for EVERY row length the instantiation is launched for (launch_mm: the smallest E that covers K, so at most
 // three registers of slack, the fourth for the upper half of the 64-lane layout, which starts at K = 897).
-template <int E, int G>
+// KC > 0: the kernel is compiled for rows of exactly KC elements (launch_mm: the reference's datasets, K = 1000 / 397 / 100),
+// and the count is exact: with the row length a constant the compiler resolves every step, tail and mask of the row sum,
+// of the placement sweeps and of the update by itself - this constant and first_ragged_register are the two places where the
+// kernels' own template arithmetic has to be told.
+template <int E, int G, int KC = 0>
 constexpr int sure_registers() {
+    if (KC > 0) {
+        const int size_ilp = (KC >> 3) >> 2;                               // steps of the 4-way interleaved part
+        if (G == 64) return size_ilp - 16 < 0 ? 0 : (size_ilp - 16 > E ? E : size_ilp - 16);     // the upper half's step of register e is 16 + e
+        if (G == 32) return size_ilp > E ? E : size_ilp;
+        const int P = 4 / (G / 8);                                          // registers per step (group_sum_torch_g)
+        return size_ilp * P > E ? E : size_ilp * P;
+    }
     if (G == 64) return (TCLIP_G64_MIN_K >= 897 && E == 16) ? 12 : 0;      // 16 + e < K / 32 for K >= 897
+    return E > 4 ? E - 4 : 0;
+}
+// registers below it hold only slots inside the row in every lane (the split kernel queues them whole)
+template <int E, int G, int KC = 0>
+constexpr int first_ragged_register() {
+    if (KC > 0) return full_registers<E, G>(KC) > E ? E : full_registers<E, G>(KC);
     return E > 4 ? E - 4 : 0;
 }
 
 // the row sum in torch's order, valid in every lane of the row's lane group
-template <int E, int G>
+template <int E, int G, int KC = 0>
 __device__ __forceinline__ float row_sum_torch_all(const float (&x)[E], int K, int lane) {
-    if constexpr (G == kGroup) return group_sum_torch<E, false, sure_registers<E, G>()>(x, K, lane);
-    else if constexpr (G == 64) return group_sum_torch_64<E, false, sure_registers<E, G>()>(x, K, lane);
-    else return group_sum_torch_g<E, G, false, sure_registers<E, G>()>(x, K, lane);
+    if constexpr (G == kGroup) return group_sum_torch<E, false, sure_registers<E, G, KC>()>(x, K, lane);
+    else if constexpr (G == 64) return group_sum_torch_64<E, false, sure_registers<E, G, KC>()>(x, K, lane);
+    else return group_sum_torch_g<E, G, false, sure_registers<E, G, KC>()>(x, K, lane);
 }
 
 template <int E, int G>
@@ -759,14 +776,14 @@ __global__ __launch_bounds__(256, (E > 16 ? TCLIP_MM_WAVES_LARGE : TCLIP_MM_WAVE
 struct QueueCtl { int count[2][8]; int bad; float rowsum[2][64]; float psi[2][64]; };
 
 // the row sum in torch's order, valid in lane 0 of the row's lane group (K >= 8; shorter rows: in every lane)
-template <int E, int G>
+template <int E, int G, int KC = 0>
 __device__ __forceinline__ float row_sum_torch(const float (&x)[E], int K, int lane) {
-    if constexpr (G == kGroup) return group_sum_torch<E, true, sure_registers<E, G>()>(x, K, lane);
-    else if constexpr (G == 64) return group_sum_torch_64<E, true, sure_registers<E, G>()>(x, K, lane);
-    else return group_sum_torch_g<E, G, true, sure_registers<E, G>()>(x, K, lane);
+    if constexpr (G == kGroup) return group_sum_torch<E, true, sure_registers<E, G, KC>()>(x, K, lane);
+    else if constexpr (G == 64) return group_sum_torch_64<E, true, sure_registers<E, G, KC>()>(x, K, lane);
+    else return group_sum_torch_g<E, G, true, sure_registers<E, G, KC>()>(x, K, lane);
 }
 
-template <int E, int W, int R, int G>
+template <int E, int W, int R, int G, int KC = 0>
 __device__ __forceinline__ void mm_iterate_block(float (&beta)[R][E], const RowY<E, G> (&yv)[R], int K, int lane,
                                                  const bool (&active)[R], const LogTabEntry* tab, float* queue, QueueCtl* ctl,
                                                  int turn, bool measure, double (&num)[R], double (&den)[R]) {
@@ -782,7 +799,7 @@ __device__ __forceinline__ void mm_iterate_block(float (&beta)[R][E], const RowY
     for (int r = 0; r < R; r++) {
         s[r] = 16.0f;
         if (active[r]) {
-            s[r] = row_sum_torch<E, G>(beta[r], K, lane);
+            s[r] = row_sum_torch<E, G, KC>(beta[r], K, lane);
             in_domain = in_domain && (lane != 0 || (fast_range_f32(s[r]) && s[r] <= 0x1p40f));     // the sum lives in lane 0
 #pragma unroll
             for (int e = 0; e < E; e++) in_domain = in_domain && mm_fast_domain(beta[r][e]);
@@ -868,7 +885,7 @@ __device__ __forceinline__ void mm_iterate_block(float (&beta)[R][E], const RowY
 // `beta_dead` (their alpha keeps its value, em_dirichlet.py:224-226) and the stop-test pair goes to the cache.
 // G: lanes per row (32; 16 or 8 for short rows, where a 32-lane group would leave lanes idle: K = 100 fills
 // 100 of 128 slots as 32 x 4 but 100 of 104 as 8 x 13, with eight rows per wavefront sharing the per-row work).
-template <int E, int W, bool kDead, int R, int G = kGroup>
+template <int E, int W, bool kDead, int R, int G = kGroup, int KC = 0>
 // wavefronts per SIMD: 4 (128 VGPRs) up to 16 registers per lane - also for K = 257..512 as 32 lanes x 10..16 since round 2
 // (K = 397, hard, 1000 tasks: 1.24 -> 1.18 s) - 3 (168 VGPRs) for the 20..28-register kernels
 __global__ __launch_bounds__(64 * W, (E > 16 ? TCLIP_MM_WAVES_LARGE : TCLIP_MM_WAVES_SMALL)) void k_mm_live(MMArgs a) {
@@ -883,7 +900,7 @@ __global__ __launch_bounds__(64 * W, (E > 16 ? TCLIP_MM_WAVES_LARGE : TCLIP_MM_W
     static_assert(kRows <= 64, "QueueCtl holds 64 row sums");
     int turn = 0;
     const int n = *a.n_rows;
-    const int K = a.K;
+    const int K = KC > 0 ? KC : a.K;               // KC: compiled for this row length (launch_mm)
     for (int first = blockIdx.x * kRows; first < n; first += gridDim.x * kRows) {   // block-uniform trip count
         int row[R];
         bool active[R];
@@ -917,7 +934,7 @@ __global__ __launch_bounds__(64 * W, (E > 16 ? TCLIP_MM_WAVES_LARGE : TCLIP_MM_W
             num[r] = den[r] = 0.0;
         }
         for (int l = a.l0; l <= a.l1; l++)
-            mm_iterate_block<E, W, R, G>(beta, yv, K, lane, active, tab, queue, &ctl, turn++, a.has_check && l == a.l1, num, den);
+            mm_iterate_block<E, W, R, G, KC>(beta, yv, K, lane, active, tab, queue, &ctl, turn++, a.has_check && l == a.l1, num, den);
 #pragma unroll
         for (int r = 0; r < R; r++) {
             if (!active[r]) continue;
@@ -1054,7 +1071,7 @@ __device__ __forceinline__ void wave_lds_handoff() {
 }
 
 // my0 / my1: the wavefront's two planes of 64 E words
-template <int E, int G>
+template <int E, int G, int KC = 0>
 __device__ __forceinline__ void mm_iterate_wave_split(float (&beta)[E], const RowY<E, G, TCLIP_SPLIT_Y_REGS_MAX_E>& yv, int K, int lane, bool active,
                                                       const LogTabEntry* tab, float* my0, float* my1, bool measure,
                                                       double& num, double& den) {
@@ -1062,7 +1079,7 @@ __device__ __forceinline__ void mm_iterate_wave_split(float (&beta)[E], const Ro
     float s = 16.0f;
     bool in_domain = true;
     if (active) {
-        s = row_sum_torch<E, G>(beta, K, lane);
+        s = row_sum_torch<E, G, KC>(beta, K, lane);
         in_domain = lane != 0 || (fast_range_f32(s) && s <= 0x1p40f);     // the sum lives in lane 0
 #pragma unroll
         for (int e = 0; e < E; e++) in_domain = in_domain && mm_fast_domain(beta[e]);
@@ -1090,7 +1107,7 @@ __device__ __forceinline__ void mm_iterate_wave_split(float (&beta)[E], const Ro
     // instantiated for the smallest E that covers K: at most three registers of slack, the fourth for the upper half of
     // the 64-lane layout); their slots are masked out of the queues, all other registers are queued whole.
     // (Lane groups without a row hold zeros and travel as class A; they only occur in the last block of a list.)
-    constexpr int kFirstRagged = E > 4 ? E - 4 : 0;
+    constexpr int kFirstRagged = first_ragged_register<E, G, KC>();
     // The same sweep notes whether any parameter is 1e-11 or less (the curvature's constant branch, em_dirichlet.py:155): phase C
     // of a wavefront without one runs without that compare and select.  A running minimum over the parameters' bit patterns
     // as signed integers (the order of the non-negative floats; -0 sorts below everything and counts as small), three values
@@ -1237,7 +1254,7 @@ __device__ __forceinline__ void mm_iterate_wave_split(float (&beta)[E], const Ro
     wave_lds_handoff();
 }
 
-template <int E, int G>
+template <int E, int G, int KC = 0>
 __global__ __launch_bounds__(64, (E > 16 ? TCLIP_MM_WAVES_LARGE : (E > 8 ? TCLIP_SPLIT_WAVES_MID : TCLIP_SPLIT_WAVES_SMALL))) void k_mm_split(MMArgs a) {
     static_assert(E <= TCLIP_SPLIT_MAX_E, "LDS: two words per element");
     __shared__ LogTabEntry tab[16];
@@ -1248,7 +1265,7 @@ __global__ __launch_bounds__(64, (E > 16 ? TCLIP_MM_WAVES_LARGE : (E > 8 ? TCLIP
     const int group = threadIdx.x / G;
     constexpr int kRows = 64 / G;
     const int n = *a.n_rows;
-    const int K = a.K;
+    const int K = KC > 0 ? KC : a.K;
     for (int first = blockIdx.x * kRows; first < n; first += gridDim.x * kRows) {
         const int i = first + group;
         const int row = i < n ? a.rows[i] : 0;
@@ -1264,7 +1281,7 @@ __global__ __launch_bounds__(64, (E > 16 ? TCLIP_MM_WAVES_LARGE : (E > 8 ? TCLIP
             beta[e] = (active && d < K) ? a.alpha[(size_t)row * K + d] : 0.0f;
         }
         for (int l = a.l0; l <= a.l1; l++)
-            mm_iterate_wave_split<E, G>(beta, yv, K, lane, active, tab, plane0, plane1, a.has_check && l == a.l1, num, den);
+            mm_iterate_wave_split<E, G, KC>(beta, yv, K, lane, active, tab, plane0, plane1, a.has_check && l == a.l1, num, den);
         if (!active) continue;
 #pragma unroll
         for (int e = 0; e < E; e++) {
@@ -2580,7 +2597,7 @@ static void dispatch_E(int K, Args... args) {
 #define TCLIP_MM_LAUNCH_WAVES 4
 #endif
 enum MMKind { kMMLive = 0, kMMDead = 1, kMMProbe = 2, kMMSplit = 3 };
-template <int E, int G>
+template <int E, int G, int KC = 0>
 static void launch_mm_EG(int dead, int rows, hipStream_t st, const MMArgs& a) {
     constexpr int kWaves = TCLIP_MM_LAUNCH_WAVES, kRowsPerBlock = (64 / G) * kWaves;
     int grid = (rows + kRowsPerBlock - 1) / kRowsPerBlock;
@@ -2590,15 +2607,15 @@ static void launch_mm_EG(int dead, int rows, hipStream_t st, const MMArgs& a) {
             constexpr int kSplitRows = 64 / G;           // one wavefront per block
             int sgrid = (rows + kSplitRows - 1) / kSplitRows;
             if (sgrid > 256 * 64) sgrid = 256 * 64;
-            hipLaunchKernelGGL((k_mm_split<E, G>), dim3(sgrid), dim3(64), 0, st, a);
+            hipLaunchKernelGGL((k_mm_split<E, G, KC>), dim3(sgrid), dim3(64), 0, st, a);
             g_last_mm_was_split = true;
             return;
         }
         dead = kMMLive;
     }
     if (dead == kMMProbe) hipLaunchKernelGGL((k_mm_probe<E, G>), dim3(grid), dim3(256), 0, st, a);
-    else if (dead) hipLaunchKernelGGL((k_mm_live<E, kWaves, true, 1, G>), dim3(grid), dim3(64 * kWaves), 0, st, a);
-    else hipLaunchKernelGGL((k_mm_live<E, kWaves, false, 1, G>), dim3(grid), dim3(64 * kWaves), 0, st, a);
+    else if (dead) hipLaunchKernelGGL((k_mm_live<E, kWaves, true, 1, G, KC>), dim3(grid), dim3(64 * kWaves), 0, st, a);
+    else hipLaunchKernelGGL((k_mm_live<E, kWaves, false, 1, G, KC>), dim3(grid), dim3(64 * kWaves), 0, st, a);
 }
 template <int G>
 static void launch_mm_G(int need, int dead, int rows, hipStream_t st, const MMArgs& a) {
@@ -2641,8 +2658,28 @@ static bool mm_has_split(int K) {
     else E = mm_regs_of((K + 31) / 32, 32);
     return E <= TCLIP_SPLIT_MAX_E && E >= TCLIP_SPLIT_MIN_E;
 }
+// Row lengths the MM kernels are also compiled for as constants - the class counts of the reference's datasets that BASELINE.json
+// runs (ImageNet 1000, SUN397 397, Caltech101-sized 100): same code, same layout as the run-time-K kernel of the row length's
+// bucket, with every mask and tail of a ragged last register resolved by the compiler (round 4: the run-time forms kept
+// 2 x 4 lane masks per row sum in spilled scalar registers).  g_fixed_k_kernels == 0 (tclip_debug_set_fixed_k_kernels, tests):
+// the run-time-K kernels for every row length, which must give the same bits.
+#ifndef TCLIP_FIXED_K_DEFAULT
+#define TCLIP_FIXED_K_DEFAULT 1
+#endif
+static int g_fixed_k_kernels = TCLIP_FIXED_K_DEFAULT;
 static void launch_mm(int dead, int K, int rows, hipStream_t st, const MMArgs& a) {
     const bool wide = g_rowset_min_rows == 0;              // test hook: the 32-lane layout for every row length
+    if (!wide && g_fixed_k_kernels && dead != kMMProbe) {
+#if TCLIP_G64_MIN_K > 0 && TCLIP_G64_MIN_K <= 1000
+        if (K == 1000) return launch_mm_EG<16, 64, 1000>(dead, rows, st, a);
+#endif
+#if TCLIP_G16_MAX_K < 397
+        if (K == 397) return launch_mm_EG<13, 32, 397>(dead, rows, st, a);
+#endif
+#if TCLIP_G16_MAX_K >= 100 && TCLIP_G8_MAX_K < 100
+        if (K == 100) return launch_mm_EG<7, 16, 100>(dead, rows, st, a);
+#endif
+    }
 #if TCLIP_G64_MIN_K > 0
     if (K >= TCLIP_G64_MIN_K && K >= 512 && !wide) return launch_mm_EG<16, 64>(dead, rows, st, a);   // 512: the cascade's first dump
 #endif
@@ -3650,6 +3687,11 @@ int tclip_debug_set_rowset_min_rows(int32_t rows) {
 int tclip_debug_set_kmeans_tile(int32_t mode) {
     g_kmeans_tile = mode;
     g_mstats_cols = mode;
+    return TCLIP_OK;
+}
+
+int tclip_debug_set_fixed_k_kernels(int32_t on) {
+    g_fixed_k_kernels = on;
     return TCLIP_OK;
 }
 
