@@ -1173,13 +1173,15 @@ __device__ __forceinline__ void mm_iterate_wave_split(float (&beta)[E], const Ro
     }
     const float psi_s = digamma_pos_f32(s, tab);                    // the row sums of the wavefront's rows, one evaluation
     wave_lds_handoff();
-    // phase B: the queues in dense passes; entry i leaves with lgamma(a+1) in plane 0 and digamma(a+1) in plane 1
+    // phase B: the queues in dense passes; entry i leaves with lgamma(a+1) in plane 0 and digamma(a+1) in plane 1.
+    // A lane beyond the end of its queue in a last, partial pass takes the queue's LAST entry along with that entry's own lane:
+    // same argument, same results, written to the same two words - so no pass needs an execution mask around its LDS
+    // read or its stores (two s_and_saveexec / s_or pairs, a compare and a default value per pass before).
     int jA = 0;
     for (; jA + 64 < nA; jA += 128) {                               // more than 64 entries left: two per lane on the packed pipe
         const int j = jA;
-        const int i0 = j + lane64, i1 = i0 + 64;
-        const bool ok0 = i0 < nA, ok1 = i1 < nA;
-        const f2 x{ok0 ? my0[i0] : 1.5f, ok1 ? my0[i1] : 1.5f};
+        const int i0 = j + lane64, i1 = min(i0 + 64, nA - 1);           // i0 < nA: the loop's condition
+        const f2 x{my0[i0], my0[i1]};
         f2 xr = x, acc = pk(0.0f);
 #pragma unroll
         for (int k = 0; k < 8; k++) {                               // x + 7 < 10: the first eight steps are always taken
@@ -1191,13 +1193,14 @@ __device__ __forceinline__ void mm_iterate_wave_split(float (&beta)[E], const Ro
         xr = xr + m;
         const f2 psi = pk_digamma_after_rec(xr, acc, tab);
         const f2 lg = pk_lgamma_sleef_1_23(x);
-        if (ok0) { my0[i0] = lg.x; my1[i0] = psi.x; }
-        if (ok1) { my0[i1] = lg.y; my1[i1] = psi.y; }
+        my0[i0] = lg.x;
+        my1[i0] = psi.x;
+        my0[i1] = lg.y;
+        my1[i1] = psi.y;
     }
     for (; jA < nA; jA += 64) {                                     // a last pass of up to 64 entries: one per lane (half the instructions)
-        const int i = jA + lane64;
-        const bool ok = i < nA;
-        const float x = ok ? my0[i] : 1.5f;
+        const int i = min(jA + lane64, nA - 1);
+        const float x = my0[i];
         float xr = x, acc = 0.0f;
 #pragma unroll
         for (int k = 0; k < 8; k++) {
@@ -1211,12 +1214,13 @@ __device__ __forceinline__ void mm_iterate_wave_split(float (&beta)[E], const Ro
         bool sure;
         float lg = lgamma_sleef_1_23_f64(x, sure);
         if (__builtin_expect(__builtin_amdgcn_ballot_w64(!sure) != 0ull, 0)) lg = sure ? lg : lgamma_sleef_05_23(x);
-        if (ok) { my0[i] = lg; my1[i] = psi; }
+        my0[i] = lg;
+        my1[i] = psi;
     }
     // (two entries per lane in these passes - two independent chains for the scheduler to interleave - measured no
     // different: K = 100 361 against 359 ms, K = 1000 equal; the passes are not latency-bound)
-    auto pass_b = [&](int i, bool ok) {                            // recurrence (eight masked steps: x + 8 >= 10) + series + general large-argument lgamma
-        const float x = ok ? my0[i] : 5.0f;
+    auto pass_b = [&](int i) {                                     // recurrence (eight masked steps: x + 8 >= 10) + series + general large-argument lgamma
+        const float x = my0[i];
         float xr = x, acc = 0.0f;
 #pragma unroll
         for (int k = 0; k < 8; k++) {
@@ -1226,7 +1230,8 @@ __device__ __forceinline__ void mm_iterate_wave_split(float (&beta)[E], const Ro
         }
         const float psi = digamma_after_rec_ge10<false>(xr, acc, tab);
         const float lg = lgamma_big_dense(x);
-        if (ok) { my0[i] = lg; my1[i] = psi; }
+        my0[i] = lg;
+        my1[i] = psi;
     };
     // When the last, partial passes of B and C fit into one (<= 64 entries together), class C's leftovers ride in B's pass:
     // the masked recurrence takes no step from 10 on and the general lgamma returns what the no-shift form returns (both are
@@ -1234,18 +1239,18 @@ __device__ __forceinline__ void mm_iterate_wave_split(float (&beta)[E], const Ro
     const int tB = nB & 63, tC = nC & 63;
     const bool merged = tB > 0 && tC > 0 && tB + tC <= 64;
     const int endB = merged ? nB - tB : nB, endC = merged ? nC - tC : nC;
-    for (int j = 0; j < endB; j += 64) pass_b(nA + j + lane64, j + lane64 < nB);
+    for (int j = 0; j < endB; j += 64) pass_b(nA + min(j + lane64, endB - 1));
     if (merged) {
-        const bool fromB = lane64 < tB;
-        pass_b(fromB ? nA + endB + lane64 : nA + nB + endC + (lane64 - tB), lane64 < tB + tC);
+        const int l = min(lane64, tB + tC - 1);
+        pass_b(l < tB ? nA + endB + l : nA + nB + endC + (l - tB));
     }
     for (int j = 0; j < endC; j += 64) {
-        const int i = nA + nB + j + lane64;
-        const bool ok = j + lane64 < nC;
-        const float x = ok ? my0[i] : 16.0f;
+        const int i = nA + nB + min(j + lane64, endC - 1);
+        const float x = my0[i];
         const float psi = digamma_after_rec_ge10<true>(x, 0.0f, tab);
         const float lg = lgamma_gt7_dense(x);
-        if (ok) { my0[i] = lg; my1[i] = psi; }
+        my0[i] = lg;
+        my1[i] = psi;
     }
     // phase C
     wave_lds_handoff();
