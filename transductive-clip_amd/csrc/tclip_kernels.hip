@@ -631,8 +631,10 @@ __device__ __forceinline__ void mm_iterate(float (&beta)[E], const RowY<E, G>& y
                                            double& den) {
     const float s = row_sum_torch_all<E, G>(beta, K, lane);
     bool in_domain = fast_range_f32(s) && s <= 0x1p40f;
+    uint32_t largest = 0u;
 #pragma unroll
-    for (int e = 0; e < E; e++) in_domain = in_domain && mm_fast_domain(beta[e]);
+    for (int e = 0; e < E; e++) largest = max(largest, f32_bits(beta[e]));
+    in_domain = in_domain & mm_fast_domain_of_max_bits(largest);
     if (__builtin_expect(!__all(in_domain), 0)) {   // NaN / inf / out of range somewhere in the wave
         const float psi_s = digamma_f32(s);
 #pragma unroll
@@ -801,8 +803,10 @@ __device__ __forceinline__ void mm_iterate_block(float (&beta)[R][E], const RowY
         if (active[r]) {
             s[r] = row_sum_torch<E, G, KC>(beta[r], K, lane);
             in_domain = in_domain && (lane != 0 || (fast_range_f32(s[r]) && s[r] <= 0x1p40f));     // the sum lives in lane 0
+            uint32_t largest = 0u;
 #pragma unroll
-            for (int e = 0; e < E; e++) in_domain = in_domain && mm_fast_domain(beta[r][e]);
+            for (int e = 0; e < E; e++) largest = max(largest, f32_bits(beta[r][e]));
+            in_domain = in_domain & mm_fast_domain_of_max_bits(largest);
         }
         if (lane == 0) ctl->rowsum[turn & 1][r * kGroups + (threadIdx.x / G)] = s[r];
         int idx = base[r];
@@ -1081,8 +1085,10 @@ __device__ __forceinline__ void mm_iterate_wave_split(float (&beta)[E], const Ro
     if (active) {
         s = row_sum_torch<E, G, KC>(beta, K, lane);
         in_domain = lane != 0 || (fast_range_f32(s) && s <= 0x1p40f);     // the sum lives in lane 0
+        uint32_t largest = 0u;
 #pragma unroll
-        for (int e = 0; e < E; e++) in_domain = in_domain && mm_fast_domain(beta[e]);
+        for (int e = 0; e < E; e++) largest = max(largest, f32_bits(beta[e]));
+        in_domain = in_domain & mm_fast_domain_of_max_bits(largest);
     }
     s = __shfl(s, 0, G);                                            // the row's sum in every lane of its group
     if (__builtin_expect(!__all(in_domain), 0)) {                   // NaN / inf / out of range somewhere in the wavefront

@@ -696,6 +696,12 @@ TCLIP_HD float exp_f32_sleef(float d) {
 // and in the range where the fast reciprocal equals the IEEE quotient); callers route anything
 // else (NaN, inf, negative, huge) to the generic routines.
 TCLIP_HD bool mm_fast_domain(float a) { return a >= 0.0f && a <= 0x1p40f; }
+// The same for a whole set of parameters from the largest of their bit patterns read as unsigned integers: +0 .. 2^40 are the
+// patterns up to 0x53800000; anything negative, infinite or NaN has a larger one.  (-0 is excluded too and goes to the generic
+// routines, which is always allowed.)  One three-way maximum per two parameters and one compare per row where the
+// element-wise form took two compares per parameter - which the compiler had turned into sixteen NESTED execution-mask
+// regions per iteration of the 16-register kernels (short-circuit &&).
+TCLIP_HD bool mm_fast_domain_of_max_bits(uint32_t largest) { return largest <= 0x53800000u; }
 
 // 1.0f where x < 10, else 0.0f, for 1 <= x <= 2^41.  Floats below 10 are at most 10 - 2^-20, so
 // (10 - x) * 2^20 is >= 1 there and <= 0 from 10 on: one fma with the clamp output modifier
