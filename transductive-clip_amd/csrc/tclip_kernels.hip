@@ -9,6 +9,9 @@
 //                     contributions are not cached yet
 //   k_mm_live x20     <=50 majorize-minimize iterations per launch for the live rows, alpha rows
 //                     register-resident, large-argument lgamma work queued block-wide in LDS
+//   k_mm_split        the same for the live rows from the second outer iteration on: every element executes only what its
+//                     value class a+1 < 2.3 / [2.3, 10) / >= 10 needs, through three dense per-wavefront LDS queues
+//                     (both also compiled with the row length as a constant for K = 1000 / 397 / 100, launch_mm)
 //   k_mm_live<dead>   the same for the listed dead rows (y = -10, iterate kept in a scratch copy),
 //   k_mm_probe        after chunk 0: limit-cycle detection that spares them the remaining chunks
 //   k_mm_decide x20   batch-global stop test on device, no host round trip          (:157-177)
