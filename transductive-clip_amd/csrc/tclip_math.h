@@ -506,7 +506,7 @@ TCLIP_HD double logk2f_f64(float hi, double val) {
 // that call need no reproduction: log1p(w) by its series to w^6 (remainder w^7 / 7 < 5e-15 against values >= lgamma(7) = 6.6),
 // six fp64 operations instead of a reciprocal, a Newton step and the polynomial.  Checked like every other form: every
 // float of (7, 2^41] against the double-float restatement (mc_lgamma_gt7_f64_form).
-// (The all-fp64 form: what log1p_small_split below was derived from and is checked against in the margin; no caller since round 4.)
+// (The all-fp64 form log1p_small_split below was derived from; no caller since round 4.)
 TCLIP_HD double log1p_small_f64(double w) {
     double p = __builtin_fma(w, -1.0 / 6.0, 1.0 / 5.0);
     p = __builtin_fma(p, w, -1.0 / 4.0);
