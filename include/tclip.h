@@ -275,6 +275,10 @@ int tclip_profile_collect(double* mm_busy_ms, double* mm_launch_ms_sum, int64_t*
 /* The same four figures of the LAST tclip_profile_collect of this thread per kernel: index 0 = k_mm_live (the first outer
  * iteration and row lengths without a split instantiation), 1 = k_mm_split.  Every argument points to two values. */
 int tclip_profile_last_kernels(double* busy_ms, double* launch_ms_sum, int64_t* launches, int64_t* element_updates);
+/* k_mm_split keeps the placement of a wavefront's elements in its three class queues from one MM iteration to the next and
+ * sorts anew only when an element has left its class: the wavefront-iterations the kernel ran in the window of the LAST
+ * tclip_profile_collect of this thread, and how many of them ran the full placement (the first of every launch does). */
+int tclip_profile_last_split_sorts(int64_t* wave_iterations, int64_t* sorts);
 
 /* Dead rows are spared the rest of their schedule once a limit-cycle probe (run after each of the
  * first `chunks` 50-iteration chunks) finds them on a cycle of the fp32 map - an exact shortcut.

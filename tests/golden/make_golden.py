@@ -159,8 +159,16 @@ LARGE = {
     #   reach of the reference on this host; the mode, not the row length, is what this fixture adds).
     "bigbatch_zs_hard_K397_N42": ("zs_hard", 397, 42, 10, 0, 2081, False),
     "bigbatch_fs_soft_K100_N170_s1": ("fs_soft", 100, 170, 20, 1, 2082, False),
+    # (round 5) the headline's own kernel combination, made by the reference: 17 tasks at K = 1000 are 17 000 rows, so the
+    # engine runs k_mm_live<16,4,false,1,64,1000> + k_mm_split<16,64,1000> + the two-stage stop test (k_mm_decide_partial) -
+    # what every batch of the K = 1000 bench runs.  The reference's (N,Q,K,K) temporary is 5.1 GB; full 20 x 1000 schedule.
+    "bigbatch_zs_soft_K1000_N17": ("zs_soft", 1000, 17, 20, 0, 2083, False),
+    # (round 5) configs[4]'s support size: ONE task at K = 1000 with 4 shots, S = 4000 support rows.  The reference's
+    # (1,S,K,K) temporary is 16 GB (few_shot/em_dirichlet.py:196-200), once per outer iteration.
+    "fs_soft_K1000_N1_s4": ("fs_soft", 1000, 1, 20, 4, 2084, False),
 }
-INTSYNTH_LEAN = {"bigbatch_zs_soft_K100_N170", "bigbatch_zs_hard_K397_N42", "bigbatch_fs_soft_K100_N170_s1"}
+INTSYNTH_LEAN = {"bigbatch_zs_soft_K100_N170", "bigbatch_zs_hard_K397_N42", "bigbatch_fs_soft_K100_N170_s1",
+                 "bigbatch_zs_soft_K1000_N17", "fs_soft_K1000_N1_s4"}
 LEAN_BOOST = 64          # soft rows: the first outer iteration of the 170-task batch stops at MM iteration 151 (boost 4096: never)
 
 
@@ -283,12 +291,14 @@ def run_case(name, spec, classes):
         out["u_sha1"] = sha(m.u.numpy())
         out["alpha_sha1"] = sha(alpha)
         rng = np.random.default_rng(seed)
-        rows = np.stack([np.sort(rng.choice(K, size=8, replace=False)) for _ in range(N)])
+        rows = np.stack([np.sort(rng.choice(K, size=(8 if N > 8 else 64), replace=False)) for _ in range(N)])
         out["alpha_rows_idx"] = rows.astype(np.int32)
         out["alpha_rows"] = np.stack([alpha[n, rows[n]] for n in range(N)])
         a64 = alpha.astype(np.float64)
         out["alpha_rowsum"] = a64.sum(-1)
         out["alpha_rowsumsq"] = (a64 * a64).sum(-1)
+        if N <= 8:
+            out["u"] = m.u.numpy()
     elif full:
         out["alpha"] = alpha
         out["u"] = m.u.numpy()

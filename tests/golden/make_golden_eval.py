@@ -72,16 +72,24 @@ def main():
     only = set(sys.argv[1:])
     cases = [("zs", False, None), ("zs", True, None), ("fs", False, None), ("fs", True, None),
              ("zs", False, "HARD_KMEANS"), ("zs", False, "EM_GAUSSIAN"), ("zs", False, "EM_GAUSSIAN_COV"), ("zs", False, "SOFT_KMEANS"), ("zs", False, "KL_KMEANS"), ("zs", False, "CLIP"), ("fs", False, "PADDLE"), ("fs", False, "BDCSPN"), ("fs", False, "ALPHA_TIM"), ("fs", False, "LAPLACIAN_SHOT")]
-    for kind, hard, other in cases:
-        K = 10
+    # (round 5) one evaluator fixture at a BASELINE class count: configs[1]'s shape, K = 100 with batch_size = 100 (two
+    # batches; the reference's (N,Q,K,K) temporary is 300 MB); selected by name only: `make_golden_eval.py K100`
+    big = {"K": 100, "number_tasks": 200, "batch_size": 100}
+    if "K100" in only:
+        only.discard("K100")
+        cases = [("zs", False, None, big)]
+    for case in cases:
+        kind, hard, other = case[:3]
+        shape = case[3] if len(case) > 3 else {"K": 10, "number_tasks": 20, "batch_size": 10}
+        K, n_tasks, bs = shape["K"], shape["number_tasks"], shape["batch_size"]
         method = other or ("HARD_EM_DIRICHLET" if hard else "EM_DIRICHLET")
         if only and method not in only and f"{kind}:{method}" not in only:
             continue
         if only and method in only and any(":" in o for o in only) and f"{kind}:{method}" not in only:
             continue
         args = Args(iter=10 if (hard or other in ("HARD_KMEANS", "KL_KMEANS")) else 20, iter_mm=1000, num_classes_test=K, n_class=K,
-                    n_query=75, k_eff=5, T=30, use_softmax_feature=True, graph_matching=True, shots=2, number_tasks=20,
-                    batch_size=10, name_method=method, used_test_set="test", tunable=False, lambd=5.0,
+                    n_query=75, k_eff=5, T=30, use_softmax_feature=True, graph_matching=True, shots=2, number_tasks=n_tasks,
+                    batch_size=bs, name_method=method, used_test_set="test", tunable=False, lambd=5.0,
                     method=method.lower(), dataset="synthetic", norm_type="L2N", temp=30.0, num_NN=1)
         model = None
         if other == "ALPHA_TIM":          # alpha_tim.yaml; the class toggles model.eval()/train(), so it needs an object
@@ -93,15 +101,27 @@ def main():
         feats, labels = synth.make_feature_table(K, 40, seed=seed)
         out = {"kind": kind, "hard": hard, "K": K, "seed": seed, "rows_per_class": 40, "method": method,
                "iters": args.iter, "lambd": args.lambd,
-               "number_tasks": 20, "batch_size": 10, "shots": 2}
+               "number_tasks": n_tasks, "batch_size": bs, "shots": 2}
         seed_all(seed)
         if kind == "zs":
             q = []
             o = record_iter(ez.SamplerQuery_zero_shot, q)
             ev = ez.Evaluator_zero_shot(device=torch.device("cpu"), args=args, log_file="/tmp/golden_eval.log")
-            acc, t = ev.evaluate_tasks(None, feats, labels)
+            per_task = []                 # every task's accuracy, as handed to compute_confidence_interval (eval_zero_shot.py:176)
+            real_ci = ez.compute_confidence_interval
+
+            def recording_ci(data, *a, **k):
+                per_task.append(np.asarray(data, np.float32).copy())
+                return real_ci(data, *a, **k)
+            ez.compute_confidence_interval = recording_ci
+            try:
+                acc, t = ev.evaluate_tasks(None, feats, labels)
+            finally:
+                ez.compute_confidence_interval = real_ci
+            if K > 10:
+                out["task_accuracy"] = np.stack(per_task)        # (batches, batch_size)
             ez.SamplerQuery_zero_shot.__iter__ = o
-            out["query_idx"] = torch.stack(q).numpy().reshape(2, 10, 75)
+            out["query_idx"] = torch.stack(q).numpy().reshape(n_tasks // bs, bs, 75)
         else:
             feats_s, labels_s = synth.make_feature_table(K, 16, seed=seed + 1)
             q, s = [], []
@@ -111,11 +131,11 @@ def main():
             acc, t = ev.evaluate_tasks(model, feats_s, labels_s, feats, labels)
             ef.SamplerQuery_few_shot.__iter__ = oq
             ef.SamplerSupport_few_shot.__iter__ = os_
-            out["query_idx"] = torch.stack(q).numpy().reshape(2, 10, 75)
-            out["support_idx"] = torch.stack(s).numpy().reshape(2, 10, -1)
+            out["query_idx"] = torch.stack(q).numpy().reshape(n_tasks // bs, bs, 75)
+            out["support_idx"] = torch.stack(s).numpy().reshape(n_tasks // bs, bs, -1)
             out["support_rows_per_class"] = 16
         out["mean_accuracy"] = np.float64(acc)
-        name = f"eval_{kind}_{'hard' if hard else 'soft'}_K10" if other is None else f"eval_{kind}_{other.lower()}_K10"
+        name = f"eval_{kind}_{'hard' if hard else 'soft'}_K{K}" if other is None else f"eval_{kind}_{other.lower()}_K{K}"
         np.savez_compressed(os.path.join(HERE, name + ".npz"), **out)
         print(name, "acc", acc, "time", t, {k: getattr(v, "shape", v) for k, v in out.items()})
 

@@ -1077,76 +1077,66 @@ __device__ __forceinline__ void wave_lds_handoff() {
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
 
-// my0 / my1: the wavefront's two planes of 64 E words
-template <int E, int G, int KC = 0>
-__device__ __forceinline__ void mm_iterate_wave_split(float (&beta)[E], const RowY<E, G, TCLIP_SPLIT_Y_REGS_MAX_E>& yv, int K, int lane, bool active,
-                                                      const LogTabEntry* tab, float* my0, float* my1, bool measure,
-                                                      double& num, double& den) {
-    const int lane64 = threadIdx.x & 63;
-    float s = 16.0f;
-    bool in_domain = true;
-    if (active) {
-        s = row_sum_torch<E, G, KC>(beta, K, lane);
-        in_domain = lane != 0 || (fast_range_f32(s) && s <= 0x1p40f);     // the sum lives in lane 0
-        uint32_t largest = 0u;
-#pragma unroll
-        for (int e = 0; e < E; e++) largest = max(largest, f32_bits(beta[e]));
-        in_domain = in_domain & mm_fast_domain_of_max_bits(largest);
-    }
-    s = __shfl(s, 0, G);                                            // the row's sum in every lane of its group
-    if (__builtin_expect(!__all(in_domain), 0)) {                   // NaN / inf / out of range somewhere in the wavefront
-        if (active) {
-            const float psi_s = digamma_f32(s);
-#pragma unroll
-            for (int e = 0; e < E; e++) {
-                const float nb = mm_update_generic(beta[e], yv.get(e), psi_s);
-                const bool ok = elem_of<E, G>(e, lane) < K;
-                if (measure && ok) {
-                    const double df = (double)nb - (double)beta[e];
-                    num += df * df;
-                    den += (double)beta[e] * (double)beta[e];
-                }
-                beta[e] = ok ? nb : 0.0f;
-            }
-        }
-        return;
-    }
-    // phase A, first sweep: the sizes of the three classes (one v_cmp per threshold writes the 64-lane mask, the counting
-    // runs on the scalar unit).  Only the last registers of a lane can hold slots beyond the row (the kernel is
-    // instantiated for the smallest E that covers K: at most three registers of slack, the fourth for the upper half of
-    // the 64-lane layout); their slots are masked out of the queues, all other registers are queued whole.
-    // (Lane groups without a row hold zeros and travel as class A; they only occur in the last block of a list.)
+// Where every element of a wavefront's rows sits in the planes: the place of element e of this lane (16 bits each, two per
+// word) and the sizes of the three queues.  A placement stays valid for as long as no element changes its class - from one
+// MM iteration to the next that is the rule, not the exception (the parameters move by 1e-4 .. 1e-7 of their value) - so
+// the kernel keeps it across the iterations of a chunk (round 5): an iteration scatters its arguments to the places of
+// the last one (one add and one LDS store per element), the dense passes check the one class condition their own form
+// depends on, and only a wavefront that met a misplaced entry sorts again (the two sweeps below, which every iteration
+// ran until round 4: 18 of 169 lane-instructions per update, most of them half-rate compares, v_mbcnt and selects).
+#ifndef TCLIP_SPLIT_LAZY
+#define TCLIP_SPLIT_LAZY 1
+#endif
+#ifdef TCLIP_PHASE_CLOCK
+// design studies only (scripts/gpu_phase_clock.py): wavefront clocks (s_memtime) spent in the parts of the split iteration,
+// summed over all wavefronts: [0] head (row sum, domain test, digamma of the row sum), [1] scatter or sort, [2] class A passes,
+// [3] class B passes, [4] class C passes, [5] phase C, [6] iterations, [7] passes abandoned (misplaced entry)
+__device__ unsigned long long g_phase_clock[8];
+#define TCLIP_CLK(i, t) do { const long long now_ = __builtin_readcyclecounter(); pl.clk[i] += now_ - (t); (t) = now_; } while (0)
+#else
+#define TCLIP_CLK(i, t) do { } while (0)
+#endif
+template <int E>
+struct SplitPlacement {
+    uint32_t slot[(E + 1) / 2];
+    int nA, nB, nC;
+    bool valid;
+    int sorts;          // full placements of this wavefront in the launch (instrumentation)
+#ifdef TCLIP_PHASE_CLOCK
+    long long clk[8];
+#endif
+};
+
+// The full placement: two sweeps over the registers.
+// First sweep: the sizes of the three classes (one v_cmp per threshold writes the 64-lane mask, the counting runs on the
+// scalar unit).  Only the last registers of a lane can hold slots beyond the row (the kernel is instantiated for the
+// smallest E that covers K: at most three registers of slack, the fourth for the upper half of the 64-lane layout); their
+// slots are masked out of the queues, all other registers are queued whole.
+// (Lane groups without a row hold zeros and travel as class A; they only occur in the last block of a list.)
+// Second sweep: every element's argument to its place in [A | B | C]; the place is kept (16 bits) for the pick-up.
+template <int E, int G, int KC>
+__device__ __forceinline__ void split_place(const float (&beta)[E], int K, int lane, float* my0, SplitPlacement<E>& pl) {
     constexpr int kFirstRagged = first_ragged_register<E, G, KC>();
-    // The same sweep notes whether any parameter is 1e-11 or less (the curvature's constant branch, em_dirichlet.py:155): phase C
-    // of a wavefront without one runs without that compare and select.  A running minimum over the parameters' bit patterns
-    // as signed integers (the order of the non-negative floats; -0 sorts below everything and counts as small), three values
-    // per instruction and no lane mask to keep - sixteen ballots lived in scalar registers the kernel does not have and went
-    // through v_writelane / v_readlane.  Slots beyond the row hold 0 and do not take part.
     int nA = 0, nC = 0, nV = kFirstRagged * 64;
-    int32_t smallest = 0x7f800000;
 #pragma unroll
     for (int e = 0; e < E; e++) {
-        const float x1 = beta[e] + 1.0f;
+        float x1 = beta[e] + 1.0f;
+        asm volatile("" : "+v"(x1));         // (also keeps the compares inside the rarely taken sort: hoisted out of the caller's loop, all 2 E of
+                                             // them ran every iteration and their masks went through v_writelane)
         unsigned long long mA = __builtin_amdgcn_ballot_w64(x1 < 2.3f), mC = __builtin_amdgcn_ballot_w64(x1 >= 10.0f);
-        int32_t bits = (int32_t)f32_bits(beta[e]);
         if (e >= kFirstRagged) {
             const bool in_row = elem_of<E, G>(e, lane) < K;
             const unsigned long long mv = __builtin_amdgcn_ballot_w64(in_row);
             mA &= mv;
             mC &= mv;
             nV += __popcll(mv);
-            bits = in_row ? bits : 0x7f800000;
         }
-        smallest = bits < smallest ? bits : smallest;
         nA += __popcll(mA);
         nC += __popcll(mC);
     }
-    const bool tiny = __builtin_amdgcn_ballot_w64(smallest <= (int32_t)0x2d2febffu) != 0ull;      // 0x2d2febff = 1e-11f
     const int nB = nV - nA - nC;                                    // NaN compares false twice: class B, in both sweeps
-    // second sweep: every element's argument to its place in [A | B | C]; the place is kept (16 bits) for the pick-up.
     // The compares are repeated on purpose (the asm keeps the compiler from holding 2 E masks in scalar registers).
     int cA = 0, cB = nA, cC = nA + nB;
-    uint32_t slot[(E + 1) / 2];
 #pragma unroll
     for (int e = 0; e < E; e++) {
         float x1 = beta[e] + 1.0f;
@@ -1174,98 +1164,204 @@ __device__ __forceinline__ void mm_iterate_wave_split(float (&beta)[E], const Ro
         } else {
             my0[idx] = x1;
         }
-        if (e & 1) slot[e >> 1] |= (uint32_t)idx << 16;
-        else slot[e >> 1] = (uint32_t)idx;
+        if (e & 1) pl.slot[e >> 1] |= (uint32_t)idx << 16;
+        else pl.slot[e >> 1] = (uint32_t)idx;
         cA += __popcll(mA);
         cB += __popcll(mB);
         cC += __popcll(mC);
     }
+    pl.nA = nA;
+    pl.nB = nB;
+    pl.nC = nC;
+}
+
+// The arguments of this iteration to the places of the last placement.
+template <int E, int G, int KC>
+__device__ __forceinline__ void split_scatter(const float (&beta)[E], int K, int lane, float* my0, const SplitPlacement<E>& pl) {
+    constexpr int kFirstRagged = first_ragged_register<E, G, KC>();
+#pragma unroll
+    for (int e = 0; e < E; e++) {
+        const float x1 = beta[e] + 1.0f;
+        const int idx = (e & 1) ? (int)(pl.slot[e >> 1] >> 16) : (int)(pl.slot[e >> 1] & 0xffffu);
+        if (e >= kFirstRagged) {
+            if (elem_of<E, G>(e, lane) < K) my0[idx] = x1;
+        } else {
+            my0[idx] = x1;
+        }
+    }
+}
+
+// my0 / my1: the wavefront's two planes of 64 E words
+template <int E, int G, int KC = 0>
+__device__ __forceinline__ void mm_iterate_wave_split(float (&beta)[E], const RowY<E, G, TCLIP_SPLIT_Y_REGS_MAX_E>& yv, int K, int lane, bool active,
+                                                      const LogTabEntry* tab, float* my0, float* my1, bool measure,
+                                                      double& num, double& den, SplitPlacement<E>& pl) {
+    const int lane64 = threadIdx.x & 63;
+#ifdef TCLIP_PHASE_CLOCK
+    long long tclk = __builtin_readcyclecounter();
+    pl.clk[6] += 1;
+#endif
+    float s = 16.0f;
+    bool in_domain = true;
+    if (active) {
+        s = row_sum_torch<E, G, KC>(beta, K, lane);
+        in_domain = lane != 0 || (fast_range_f32(s) && s <= 0x1p40f);     // the sum lives in lane 0
+        uint32_t largest = 0u;
+#pragma unroll
+        for (int e = 0; e < E; e++) largest = max(largest, f32_bits(beta[e]));
+        in_domain = in_domain & mm_fast_domain_of_max_bits(largest);
+    }
+    s = __shfl(s, 0, G);                                            // the row's sum in every lane of its group
+    if (__builtin_expect(!__all(in_domain), 0)) {                   // NaN / inf / out of range somewhere in the wavefront
+        if (active) {
+            const float psi_s = digamma_f32(s);
+#pragma unroll
+            for (int e = 0; e < E; e++) {
+                const float nb = mm_update_generic(beta[e], yv.get(e), psi_s);
+                const bool ok = elem_of<E, G>(e, lane) < K;
+                if (measure && ok) {
+                    const double df = (double)nb - (double)beta[e];
+                    num += df * df;
+                    den += (double)beta[e] * (double)beta[e];
+                }
+                beta[e] = ok ? nb : 0.0f;
+            }
+        }
+        pl.valid = false;                                           // the generic path keeps no placement
+        return;
+    }
+    // Is any parameter 1e-11 or less (the curvature's constant branch, em_dirichlet.py:155)?  Phase C of a wavefront without
+    // one runs without that compare and select.  A running minimum over the parameters' bit patterns as signed integers (the
+    // order of the non-negative floats; -0 sorts below everything and counts as small), three values per instruction and no
+    // lane mask to keep - sixteen ballots lived in scalar registers the kernel does not have and went through v_writelane /
+    // v_readlane.  Slots beyond the row hold 0 and do not take part.
+    constexpr int kFirstRagged = first_ragged_register<E, G, KC>();
+    int32_t smallest = 0x7f800000;
+#pragma unroll
+    for (int e = 0; e < E; e++) {
+        int32_t bits = (int32_t)f32_bits(beta[e]);
+        if (e >= kFirstRagged) bits = elem_of<E, G>(e, lane) < K ? bits : 0x7f800000;
+        smallest = bits < smallest ? bits : smallest;
+    }
+    const bool tiny = __builtin_amdgcn_ballot_w64(smallest <= (int32_t)0x2d2febffu) != 0ull;      // 0x2d2febff = 1e-11f
     const float psi_s = digamma_pos_f32(s, tab);                    // the row sums of the wavefront's rows, one evaluation
-    wave_lds_handoff();
-    // phase B: the queues in dense passes; entry i leaves with lgamma(a+1) in plane 0 and digamma(a+1) in plane 1.
-    // A lane beyond the end of its queue in a last, partial pass takes the queue's LAST entry along with that entry's own lane:
-    // same argument, same results, written to the same two words - so no pass needs an execution mask around its LDS
-    // read or its stores (two s_and_saveexec / s_or pairs, a compare and a default value per pass before).
-    int jA = 0;
-    for (; jA + 64 < nA; jA += 128) {                               // more than 64 entries left: two per lane on the packed pipe
-        const int j = jA;
-        const int i0 = j + lane64, i1 = min(i0 + 64, nA - 1);           // i0 < nA: the loop's condition
-        const f2 x{my0[i0], my0[i1]};
-        f2 xr = x, acc = pk(0.0f);
+    // phase A + phase B, until the dense passes have met every entry in a queue whose form is the one for its value
+    bool sort_now = !(TCLIP_SPLIT_LAZY && pl.valid);
+    TCLIP_CLK(0, tclk);
+    for (;;) {
+        if (sort_now) {
+            split_place<E, G, KC>(beta, K, lane, my0, pl);
+            pl.sorts++;
+        } else split_scatter<E, G, KC>(beta, K, lane, my0, pl);
+        const int nA = pl.nA, nB = pl.nB, nC = pl.nC;
+        wave_lds_handoff();
+        TCLIP_CLK(1, tclk);
+        // phase B: the queues in dense passes; entry i leaves with lgamma(a+1) in plane 0 and digamma(a+1) in plane 1.
+        // A lane beyond the end of its queue in a last, partial pass takes the queue's LAST entry along with that entry's own lane:
+        // same argument, same results, written to the same two words - so no pass needs an execution mask around its LDS
+        // read or its stores (two s_and_saveexec / s_or pairs, a compare and a default value per pass before).
+        // Each pass first checks the condition its form depends on - A: x < 2.3 (the polynomial lgamma, eight unmasked
+        // recurrence steps), B: x >= 2.3 (its masked recurrence and general lgamma are right from 10 on as well: an entry
+        // that has grown past 10 stays until the next sort), C: x >= 10 (no recurrence) - and leaves at once when an entry
+        // placed by an earlier iteration has left its class.
+        bool misplaced = false;
+        int jA = 0;
+        for (; jA + 64 < nA; jA += 128) {                           // more than 64 entries left: two per lane on the packed pipe
+            const int j = jA;
+            const int i0 = j + lane64, i1 = min(i0 + 64, nA - 1);       // i0 < nA: the loop's condition
+            const f2 x{my0[i0], my0[i1]};
+            if (!sort_now && __builtin_amdgcn_ballot_w64(!(fmaxf(x.x, x.y) < 2.3f)) != 0ull) { misplaced = true; break; }
+            f2 xr = x, acc = pk(0.0f);
 #pragma unroll
-        for (int k = 0; k < 8; k++) {                               // x + 7 < 10: the first eight steps are always taken
-            acc = acc - pk_rcp_rn(xr);
-            xr = xr + pk(1.0f);
+            for (int k = 0; k < 8; k++) {                           // x + 7 < 10: the first eight steps are always taken
+                acc = acc - pk_rcp_rn(xr);
+                xr = xr + pk(1.0f);
+            }
+            const f2 m{below10_f32(xr.x), below10_f32(xr.y)};
+            acc = pk_fma(-m, pk_rcp_rn(xr), acc);
+            xr = xr + m;
+            const f2 psi = pk_digamma_after_rec(xr, acc, tab);
+            const f2 lg = pk_lgamma_sleef_1_23(x);
+            my0[i0] = lg.x;
+            my1[i0] = psi.x;
+            my0[i1] = lg.y;
+            my1[i1] = psi.y;
         }
-        const f2 m{below10_f32(xr.x), below10_f32(xr.y)};
-        acc = pk_fma(-m, pk_rcp_rn(xr), acc);
-        xr = xr + m;
-        const f2 psi = pk_digamma_after_rec(xr, acc, tab);
-        const f2 lg = pk_lgamma_sleef_1_23(x);
-        my0[i0] = lg.x;
-        my1[i0] = psi.x;
-        my0[i1] = lg.y;
-        my1[i1] = psi.y;
-    }
-    for (; jA < nA; jA += 64) {                                     // a last pass of up to 64 entries: one per lane (half the instructions)
-        const int i = min(jA + lane64, nA - 1);
-        const float x = my0[i];
-        float xr = x, acc = 0.0f;
+        for (; !misplaced && jA < nA; jA += 64) {                   // a last pass of up to 64 entries: one per lane (half the instructions)
+            const int i = min(jA + lane64, nA - 1);
+            const float x = my0[i];
+            if (!sort_now && __builtin_amdgcn_ballot_w64(!(x < 2.3f)) != 0ull) { misplaced = true; break; }
+            float xr = x, acc = 0.0f;
 #pragma unroll
-        for (int k = 0; k < 8; k++) {
-            acc = acc - rcp_rn_f32(xr);
-            xr = xr + 1.0f;
-        }
-        const float m = below10_f32(xr);
-        acc = __builtin_fmaf(-m, rcp_rn_f32(xr), acc);
-        xr = xr + m;
-        const float psi = digamma_after_rec_ge10<false>(xr, acc, tab);
-        bool sure;
-        float lg = lgamma_sleef_1_23_f64(x, sure);
-        if (__builtin_expect(__builtin_amdgcn_ballot_w64(!sure) != 0ull, 0)) lg = sure ? lg : lgamma_sleef_05_23(x);
-        my0[i] = lg;
-        my1[i] = psi;
-    }
-    // (two entries per lane in these passes - two independent chains for the scheduler to interleave - measured no
-    // different: K = 100 361 against 359 ms, K = 1000 equal; the passes are not latency-bound)
-    auto pass_b = [&](int i) {                                     // recurrence (eight masked steps: x + 8 >= 10) + series + general large-argument lgamma
-        const float x = my0[i];
-        float xr = x, acc = 0.0f;
-#pragma unroll
-        for (int k = 0; k < 8; k++) {
+            for (int k = 0; k < 8; k++) {
+                acc = acc - rcp_rn_f32(xr);
+                xr = xr + 1.0f;
+            }
             const float m = below10_f32(xr);
             acc = __builtin_fmaf(-m, rcp_rn_f32(xr), acc);
-            xr += m;
+            xr = xr + m;
+            const float psi = digamma_after_rec_ge10<false>(xr, acc, tab);
+            bool sure;
+            float lg = lgamma_sleef_1_23_f64(x, sure);
+            if (__builtin_expect(__builtin_amdgcn_ballot_w64(!sure) != 0ull, 0)) lg = sure ? lg : lgamma_sleef_05_23(x);
+            my0[i] = lg;
+            my1[i] = psi;
         }
-        const float psi = digamma_after_rec_ge10<false>(xr, acc, tab);
-        const float lg = lgamma_big_dense(x);
-        my0[i] = lg;
-        my1[i] = psi;
-    };
-    // When the last, partial passes of B and C fit into one (<= 64 entries together), class C's leftovers ride in B's pass:
-    // the masked recurrence takes no step from 10 on and the general lgamma returns what the no-shift form returns (both are
-    // RN32 of Sleef's value), so the entries get the same bits for the price of one pass instead of two.
-    const int tB = nB & 63, tC = nC & 63;
-    const bool merged = tB > 0 && tC > 0 && tB + tC <= 64;
-    const int endB = merged ? nB - tB : nB, endC = merged ? nC - tC : nC;
-    for (int j = 0; j < endB; j += 64) pass_b(nA + min(j + lane64, endB - 1));
-    if (merged) {
-        const int l = min(lane64, tB + tC - 1);
-        pass_b(l < tB ? nA + endB + l : nA + nB + endC + (l - tB));
+        TCLIP_CLK(2, tclk);
+        // (two entries per lane in these passes - two independent chains for the scheduler to interleave - measured no
+        // different: K = 100 361 against 359 ms, K = 1000 equal; the passes are not latency-bound)
+        auto pass_b = [&](int i) -> bool {                          // recurrence (eight masked steps: x + 8 >= 10) + series + general large-argument lgamma
+            const float x = my0[i];
+            if (!sort_now && __builtin_amdgcn_ballot_w64(!(x >= 2.3f)) != 0ull) return true;
+            float xr = x, acc = 0.0f;
+#pragma unroll
+            for (int k = 0; k < 8; k++) {
+                const float m = below10_f32(xr);
+                acc = __builtin_fmaf(-m, rcp_rn_f32(xr), acc);
+                xr += m;
+            }
+            const float psi = digamma_after_rec_ge10<false>(xr, acc, tab);
+            const float lg = lgamma_big_dense(x);
+            my0[i] = lg;
+            my1[i] = psi;
+            return false;
+        };
+        // When the last, partial passes of B and C fit into one (<= 64 entries together), class C's leftovers ride in B's pass:
+        // the masked recurrence takes no step from 10 on and the general lgamma returns what the no-shift form returns (both are
+        // RN32 of Sleef's value), so the entries get the same bits for the price of one pass instead of two.
+        const int tB = nB & 63, tC = nC & 63;
+        const bool merged = tB > 0 && tC > 0 && tB + tC <= 64;
+        const int endB = merged ? nB - tB : nB, endC = merged ? nC - tC : nC;
+        for (int j = 0; !misplaced && j < endB; j += 64) misplaced = pass_b(nA + min(j + lane64, endB - 1));
+        if (merged && !misplaced) {
+            const int l = min(lane64, tB + tC - 1);
+            misplaced = pass_b(l < tB ? nA + endB + l : nA + nB + endC + (l - tB));
+        }
+        TCLIP_CLK(3, tclk);
+        for (int j = 0; !misplaced && j < endC; j += 64) {
+            const int i = nA + nB + min(j + lane64, endC - 1);
+            const float x = my0[i];
+            if (!sort_now && __builtin_amdgcn_ballot_w64(!(x >= 10.0f)) != 0ull) { misplaced = true; break; }
+            const float psi = digamma_after_rec_ge10<true>(x, 0.0f, tab);
+            const float lg = lgamma_gt7_dense(x);
+            my0[i] = lg;
+            my1[i] = psi;
+        }
+        TCLIP_CLK(4, tclk);
+        if (!misplaced) break;
+#ifdef TCLIP_PHASE_CLOCK
+        pl.clk[7] += 1;
+#endif
+        sort_now = true;                                            // (the passes of a fresh placement check nothing: this loop runs twice at most)
+        wave_lds_handoff();
     }
-    for (int j = 0; j < endC; j += 64) {
-        const int i = nA + nB + min(j + lane64, endC - 1);
-        const float x = my0[i];
-        const float psi = digamma_after_rec_ge10<true>(x, 0.0f, tab);
-        const float lg = lgamma_gt7_dense(x);
-        my0[i] = lg;
-        my1[i] = psi;
-    }
+    pl.valid = true;
     // phase C
     wave_lds_handoff();
-    if (__builtin_expect(tiny, 0)) split_apply_updates<E, G, true>(beta, yv, K, lane, psi_s, my0, my1, slot, measure, num, den);
-    else split_apply_updates<E, G, false>(beta, yv, K, lane, psi_s, my0, my1, slot, measure, num, den);
+    if (__builtin_expect(tiny, 0)) split_apply_updates<E, G, true>(beta, yv, K, lane, psi_s, my0, my1, pl.slot, measure, num, den);
+    else split_apply_updates<E, G, false>(beta, yv, K, lane, psi_s, my0, my1, pl.slot, measure, num, den);
     wave_lds_handoff();
+    TCLIP_CLK(5, tclk);
 }
 
 template <int E, int G, int KC = 0>
@@ -1294,8 +1390,14 @@ __global__ __launch_bounds__(64, (E > 16 ? TCLIP_MM_WAVES_LARGE : (E > 8 ? TCLIP
             const int d = elem_of<E, G>(e, lane);
             beta[e] = (active && d < K) ? a.alpha[(size_t)row * K + d] : 0.0f;
         }
+        SplitPlacement<E> pl;
+        pl.valid = false;
+        pl.sorts = 0;
+#ifdef TCLIP_PHASE_CLOCK
+        for (int i = 0; i < 8; i++) pl.clk[i] = 0;
+#endif
         for (int l = a.l0; l <= a.l1; l++)
-            mm_iterate_wave_split<E, G, KC>(beta, yv, K, lane, active, tab, plane0, plane1, a.has_check && l == a.l1, num, den);
+            mm_iterate_wave_split<E, G, KC>(beta, yv, K, lane, active, tab, plane0, plane1, a.has_check && l == a.l1, num, den, pl);
         if (!active) continue;
 #pragma unroll
         for (int e = 0; e < E; e++) {
@@ -1304,6 +1406,14 @@ __global__ __launch_bounds__(64, (E > 16 ? TCLIP_MM_WAVES_LARGE : (E > 8 ? TCLIP
         }
         if (a.work_counter && lane == 0)
             atomicAdd(a.work_counter, (unsigned long long)K * (unsigned long long)(a.l1 - a.l0 + 1));
+#ifdef TCLIP_PHASE_CLOCK
+        if ((threadIdx.x & 63) == 0)
+            for (int i = 0; i < 8; i++) atomicAdd(&g_phase_clock[i], (unsigned long long)pl.clk[i]);
+#endif
+        if (a.work_counter && (threadIdx.x & 63) == 0) {           // [1]: wavefront-iterations of this kernel, [2]: full placements among them
+            atomicAdd(a.work_counter + 1, (unsigned long long)(a.l1 - a.l0 + 1));
+            atomicAdd(a.work_counter + 2, (unsigned long long)pl.sorts);
+        }
         if (a.has_check) {
             const double sn = group_sum_f64_g<G>(num), sd = group_sum_f64_g<G>(den);
             if (lane == 0) {
@@ -1314,6 +1424,17 @@ __global__ __launch_bounds__(64, (E > 16 ? TCLIP_MM_WAVES_LARGE : (E > 8 ? TCLIP
     }
 }
 
+#ifdef TCLIP_ISA_ONLY
+// ISA studies (scripts/isa_one.sh): only the K = 1000 MM kernels are instantiated - seconds instead of two minutes per compile.
+// Never part of a build of the library.
+template __global__ void k_mm_split<16, 64, 1000>(MMArgs);
+template __global__ void k_mm_live<16, 4, false, 1, 64, 1000>(MMArgs);
+#ifdef TCLIP_ISA_K100
+template __global__ void k_mm_split<7, 16, 100>(MMArgs);
+template __global__ void k_mm_split<13, 32, 397>(MMArgs);
+#endif
+}  // namespace tclip
+#else
 // Batch-global stop test (em_dirichlet.py:169-175), one block per batch:
 //   crit = ||b'-b||_F^2 / ||b||_F^2 over all N*K*K entries of the batch;  stop if < 1e-11.
 // fp64 accumulation in a fixed order; the final arithmetic follows the reference's fp32 form
@@ -2412,6 +2533,27 @@ __global__ void k_selftest(unsigned long long* out) {
             b4 += f32_bits(un.x) != f32_bits(us.x) || f32_bits(un.y) != f32_bits(us.y);
         }
     }
+    // (4, continued) total cancellation beside a slot beyond the row: component x has lgamma(a+1) == digamma(a+1) * a handed in, so
+    // t == 0, curvature 0 and deno == 0 (the reference's quotient is nume * inf: +inf or NaN); component y is what a ragged
+    // register pair holds beyond the row, a == 0, whose curvature without the small-parameter select is NaN.  The form without
+    // the select must still give component x what the form with it gives (round 4 tested deno.x * deno.y == 0: NaN hid the zero).
+    for (uint32_t i = tid; i < (1u << 18); i += nth) {
+        const float a = rand_float(i, 5u, -30, 34);                    // 2^-30 .. 2^4 > 1e-11
+        const uint32_t h = mix32(i * 11u + 5u);
+        const float y = -0.001f - 40.0f * (float)(h & 0xffffu) / 65536.0f;
+        const float ps = 0.5f + 14.0f * (float)(h >> 16) / 65536.0f;
+        const float p = ((i & 1u) ? 1.0f : -1.0f) * rand_float(i, 6u, -8, 14);
+        const float l = p * a;
+        float p0, l0;
+        digamma_lgamma_xp1(0.0f, tab, p0, l0);
+        const f2 av{a, 0.0f}, yy{y, 0.0f};
+        const f2 us = pk_mm_update_stage2(pk_mm_update_stage1_given<true>(av, yy, ps, p, p0, l, l0));
+        const f2 un = pk_mm_update_stage2(pk_mm_update_stage1_given<false>(av, yy, ps, p, p0, l, l0));
+        b4 += !(f32_bits(un.x) == f32_bits(us.x) || (un.x != un.x && us.x != us.x));
+        b4 += !(us.x != us.x || __builtin_fabsf(us.x) == __builtin_inff());   // nume * inf
+        const f2 vs = pk_mm_update_stage2(pk_mm_update_stage1_given<false>(f2{0.0f, a}, f2{0.0f, y}, ps, p0, p, l0, l));   // the other order
+        b4 += !(f32_bits(vs.y) == f32_bits(us.x) || (vs.y != vs.y && us.x != us.x));
+    }
     // (3, continued) the fp64 form of lgamma on every float of [1, 2.3): where it is sure it must agree
     for (uint32_t b = f32_bits(1.0f) + tid; b < f32_bits(2.3f); b += nth) {
         const float x = bits_f32(b);
@@ -2497,10 +2639,11 @@ struct Profile {
     std::vector<hipEvent_t> ev;      // start/stop pairs, reused across collections
     std::vector<uint8_t> kind;       // per pair: 0 = k_mm_live, 1 = k_mm_split
     size_t used = 0;
-    unsigned long long* counter = nullptr;      // [2]: element-updates executed by k_mm_live / k_mm_split
+    unsigned long long* counter = nullptr;      // [4]: element-updates executed by k_mm_live / k_mm_split; k_mm_split's wavefront-iterations / full placements
     // per-kernel figures of the last collection (tclip_profile_last_kernels)
     double last_busy[2] = {0, 0}, last_sum[2] = {0, 0};
     int64_t last_launches[2] = {0, 0}, last_updates[2] = {0, 0};
+    int64_t last_split_iterations = 0, last_split_sorts = 0;     // k_mm_split: wavefront-iterations, and how many of them sorted their queues anew
 };
 static thread_local bool g_last_mm_was_split = false;     // which kernel the last launch_mm(kMMSplit / kMMLive) started
 thread_local Profile g_prof;
@@ -3191,7 +3334,27 @@ static int stream_groups() {
     }();
     return n;
 }
+// TCLIP_GROUP_SIZES="5,3,2" (tuning knob): the batches of a call that has exactly their sum, dealt to the groups in these sizes
+struct GroupSizes { int n = 0, size[kMaxGroups] = {}, total = 0; };
+static const GroupSizes& group_sizes_override() {
+    static const GroupSizes gs = [] {
+        GroupSizes r;
+        const char* e = getenv("TCLIP_GROUP_SIZES");
+        while (e && *e && r.n < kMaxGroups) {
+            const int v = atoi(e);
+            if (v < 1) { r = GroupSizes(); break; }
+            r.size[r.n++] = v;
+            r.total += v;
+            while (*e && *e != ',') e++;
+            if (*e == ',') e++;
+        }
+        return r;
+    }();
+    return gs;
+}
 static int n_groups_of(const tclip_problem& p) {
+    const GroupSizes& o = group_sizes_override();
+    if (o.n > 0 && o.total == p.n_batches) return o.n;
     const long long rows = (long long)p.n_batches * p.tasks_per_batch * p.n_class;
     long long g = rows / 8192;                                   // a group should fill the machine once
     if (g > stream_groups()) g = stream_groups();
@@ -3200,8 +3363,16 @@ static int n_groups_of(const tclip_problem& p) {
 }
 
 static tclip_problem group_problem(const tclip_problem& p, int g, int* first_batch) {
-    const int G = n_groups_of(p), base = p.n_batches / G, extra = p.n_batches % G;
     tclip_problem q = p;
+    const GroupSizes& o = group_sizes_override();
+    if (o.n > 0 && o.total == p.n_batches) {
+        int b0 = 0;
+        for (int i = 0; i < g; i++) b0 += o.size[i];
+        q.n_batches = o.size[g];
+        *first_batch = b0;
+        return q;
+    }
+    const int G = n_groups_of(p), base = p.n_batches / G, extra = p.n_batches % G;
     q.n_batches = base + (g < extra ? 1 : 0);
     *first_batch = g * base + (g < extra ? g : extra);
     return q;
@@ -3725,8 +3896,8 @@ int tclip_debug_set_probe_chunks(int32_t chunks) {
 
 int tclip_profile_enable(int on) {
     if (on && !g_prof.counter) {
-        TCLIP_HIP(hipMalloc((void**)&g_prof.counter, 2 * sizeof(unsigned long long)));
-        TCLIP_HIP(hipMemset(g_prof.counter, 0, 2 * sizeof(unsigned long long)));
+        TCLIP_HIP(hipMalloc((void**)&g_prof.counter, 4 * sizeof(unsigned long long)));
+        TCLIP_HIP(hipMemset(g_prof.counter, 0, 4 * sizeof(unsigned long long)));
     }
     g_prof.on = on != 0;
     return TCLIP_OK;
@@ -3772,13 +3943,15 @@ int tclip_profile_collect(double* mm_busy_ms, double* mm_launch_ms_sum, int64_t*
     if (mm_busy_ms) *mm_busy_ms = busy;
     if (mm_launch_ms_sum) *mm_launch_ms_sum = sum;
     if (mm_launches) *mm_launches = (int64_t)(g_prof.used / 2);
-    unsigned long long c[2] = {0, 0};
+    unsigned long long c[4] = {0, 0, 0, 0};
     if (g_prof.counter) {
         TCLIP_HIP(hipMemcpy(c, g_prof.counter, sizeof c, hipMemcpyDeviceToHost));
         TCLIP_HIP(hipMemset(g_prof.counter, 0, sizeof c));
     }
     g_prof.last_updates[0] = (int64_t)c[0];
     g_prof.last_updates[1] = (int64_t)c[1];
+    g_prof.last_split_iterations = (int64_t)c[2];
+    g_prof.last_split_sorts = (int64_t)c[3];
     if (element_updates) *element_updates = (int64_t)(c[0] + c[1]);
     g_prof.used = 0;
     return TCLIP_OK;
@@ -3790,6 +3963,23 @@ int tclip_profile_last_kernels(double* busy_ms, double* launch_ms_sum, int64_t* 
         if (launches) launches[k] = g_prof.last_launches[k];
         if (element_updates) element_updates[k] = g_prof.last_updates[k];
     }
+    return TCLIP_OK;
+}
+
+#ifdef TCLIP_PHASE_CLOCK
+int tclip_debug_phase_clock(uint64_t* out) {        // reads and clears g_phase_clock (only in builds with -DTCLIP_PHASE_CLOCK)
+    TCLIP_HIP(hipDeviceSynchronize());
+    unsigned long long h[8];
+    TCLIP_HIP(hipMemcpyFromSymbol(h, HIP_SYMBOL(tclip::g_phase_clock), sizeof h));
+    for (int i = 0; i < 8; i++) out[i] = h[i];
+    memset(h, 0, sizeof h);
+    TCLIP_HIP(hipMemcpyToSymbol(HIP_SYMBOL(tclip::g_phase_clock), h, sizeof h));
+    return TCLIP_OK;
+}
+#endif
+int tclip_profile_last_split_sorts(int64_t* wave_iterations, int64_t* sorts) {
+    if (wave_iterations) *wave_iterations = g_prof.last_split_iterations;
+    if (sorts) *sorts = g_prof.last_split_sorts;
     return TCLIP_OK;
 }
 
@@ -3853,3 +4043,4 @@ int tclip_gather_rows(const float* table, int64_t n_rows, int32_t K, const int64
 
 #include "tclip_tim.inc"
 #include "tclip_lshot.inc"
+#endif  // TCLIP_ISA_ONLY

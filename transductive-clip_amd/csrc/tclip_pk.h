@@ -251,10 +251,12 @@ __device__ __forceinline__ f2 pk_sqrt_torch_inrange(f2 x) {
 __device__ __forceinline__ f2 pk_t_of(f2 lg1, f2 m) { return m - lg1; }
 
 // the quotient nume / deno of the update with the reference's IEEE behaviour at deno == 0 (total cancellation in t:
-// +-inf or nan); the zero test is wave-uniform - a product that underflows only sends the wavefront through the selects
+// +-inf or nan); the zero test is wave-uniform and per pair: min(|deno.x|, |deno.y|) == 0.  (Until round 5 it tested the
+// PRODUCT of the two, which a NaN partner hides: the slot beyond the row of a ragged register pair holds a = 0, whose
+// curvature without the small-parameter select is (|t| + |t|) / 0 = NaN.  v_min_f32 returns the other operand for a NaN.)
 __device__ __forceinline__ f2 pk_update_quotient(f2 nume, f2 deno) {
     f2 q = pk_div_rn(nume, deno);
-    if (__builtin_expect(__builtin_amdgcn_ballot_w64(deno.x * deno.y == 0.0f) != 0ull, 0))
+    if (__builtin_expect(__builtin_amdgcn_ballot_w64(__builtin_fminf(__builtin_fabsf(deno.x), __builtin_fabsf(deno.y)) == 0.0f) != 0ull, 0))
         q = pk_sel(deno == pk(0.0f), nume * pk(__builtin_inff()), q);
     return q;
 }

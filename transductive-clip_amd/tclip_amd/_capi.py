@@ -62,6 +62,7 @@ _SIGNATURES = {
     "tclip_debug_set_kmeans_tile": (ctypes.c_int, [ctypes.c_int32]),
     "tclip_profile_last_kernels": (ctypes.c_int, [ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_double),
                                                   ctypes.POINTER(ctypes.c_int64), ctypes.POINTER(ctypes.c_int64)]),
+    "tclip_profile_last_split_sorts": (ctypes.c_int, [ctypes.POINTER(ctypes.c_int64), ctypes.POINTER(ctypes.c_int64)]),
     "tclip_profile_collect": (ctypes.c_int, [ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_double),
                                              ctypes.POINTER(ctypes.c_int64), ctypes.POINTER(ctypes.c_int64)]),
 }

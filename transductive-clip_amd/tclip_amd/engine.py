@@ -361,3 +361,11 @@ def profile_last_kernels():
     n, upd = (ctypes.c_int64 * 2)(), (ctypes.c_int64 * 2)()
     _capi.check(_capi.lib().tclip_profile_last_kernels(busy, total, n, upd), "tclip_profile_last_kernels")
     return {name: (busy[i], total[i], n[i], upd[i]) for i, name in enumerate(("k_mm_live", "k_mm_split"))}
+
+
+def profile_last_split_sorts():
+    """(wavefront-iterations k_mm_split ran, full placements among them) of the last profile_collect(): the kernel keeps
+    the placement of its elements in the class queues across MM iterations and sorts anew only when one has left its class"""
+    it, so = ctypes.c_int64(0), ctypes.c_int64(0)
+    _capi.check(_capi.lib().tclip_profile_last_split_sorts(ctypes.byref(it), ctypes.byref(so)), "tclip_profile_last_split_sorts")
+    return it.value, so.value
