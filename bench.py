@@ -139,35 +139,71 @@ def cpu_baseline(w, mm_schedule, budget_s=300, iters_total=ITERS):
                                    warm=True, shots=shots_, hard=hard, k_eff=k_eff, mem_gb=40)
         out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=budget_s)
         return json.loads(out.stdout.strip().splitlines()[-1])
-    try:
-        info = child(sample_shots, 5 if shots else None)
-    except Exception as e:  # timeout or failure: report it, never fake a number
-        return {"value": None, "unit": "tasks/s", "cores": threads, "kind": "port",
-                "sample": f"not measured: {type(e).__name__} within {budget_s}s budget"}
-    sec = info["seconds"]
-    ran, t_mm, t_iter = sec["ran"], sec["mm"], sec["iter"]
-    mm_first = t_mm[0] / max(ran[0], 1)                             # one MM iteration, first outer iteration (every class alive, alpha near 1)
-    mm_later = t_mm[1] / max(ran[1], 1)                             # one MM iteration, second outer iteration
-    per_me = 0.5 * ((t_iter[0] - t_mm[0]) + (t_iter[1] - t_mm[1]))  # M-step statistics + E-step + criterion, once per outer iteration
-    note = ""
-    if sample_shots != shots:                                       # support statistics are linear in S = K * shots
-        try:
+    host = host_description(usable)
+    per_me_zs = None
+    if sample_shots != shots:                                       # support statistics are linear in S = K * shots: their share of the
+        try:                                                        # M/E-step is what a zero-shot run of the same sample does not spend
             zs = child(0, 5)["seconds"]
             per_me_zs = 0.5 * ((zs["iter"][0] - zs["mm"][0]) + (zs["iter"][1] - zs["mm"][1]))
         except Exception:
             per_me_zs = 0.0
-        support_part = max(per_me - per_me_zs, 0.0)
-        note = (f"; sampled at {sample_shots} shot (M/E-step {per_me:.2f}s, of which support statistics {support_part:.2f}s, "
-                f"linear in S) and scaled to {shots} shots")
-        per_me = per_me_zs + support_part * shots / sample_shots
-    total = len(mm_schedule) * per_me + mm_schedule[0] * mm_first + sum(mm_schedule[1:]) * mm_later
-    return {"value": n_tasks / total, "unit": "tasks/s", "cores": info["threads"], "kind": "port",
-            "sample": f"{n_tasks}-task batch of the same K={K}, 75-query workload: one run of 2 outer iterations with {ran} MM iterations "
-                      f"({sum(t_iter):.1f}s), MM loops {t_mm[0]:.2f}s / {t_mm[1]:.2f}s -> {1e3 * mm_first:.2f} / {1e3 * mm_later:.2f} ms per MM "
-                      f"iteration in the first / a later outer iteration, {per_me:.2f}s per M/E-step{note}; extrapolated over the recorded "
-                      f"schedule ({mm_schedule[0]} + {int(sum(mm_schedule[1:]))} MM iterations in {len(mm_schedule)} outer iterations) = "
-                      f"{total:.0f}s (SURVEY.md 8d); torch {info['torch']} CPU eager",
+    # TWO samples of the same workload, one after the other: the figure is their mean and the line carries both, so that a
+    # host whose other tenants came and went during the run shows up as spread instead of as a different number per box
+    values, texts, info = [], [], None
+    for rep in range(2):
+        try:
+            info = child(sample_shots, 5 if shots else None)
+        except Exception as e:  # timeout or failure: report it, never fake a number
+            if values:
+                texts.append(f"second sample not measured: {type(e).__name__} within {budget_s}s budget")
+                break
+            return {"value": None, "unit": "tasks/s", "cores": threads, "kind": "port", **host,
+                    "sample": f"not measured: {type(e).__name__} within {budget_s}s budget"}
+        sec = info["seconds"]
+        ran, t_mm, t_iter = sec["ran"], sec["mm"], sec["iter"]
+        mm_first = t_mm[0] / max(ran[0], 1)                         # one MM iteration, first outer iteration (every class alive, alpha near 1)
+        mm_later = t_mm[1] / max(ran[1], 1)                         # one MM iteration, second outer iteration
+        per_me = 0.5 * ((t_iter[0] - t_mm[0]) + (t_iter[1] - t_mm[1]))  # M-step statistics + E-step + criterion, once per outer iteration
+        note = ""
+        if per_me_zs is not None:
+            support_part = max(per_me - per_me_zs, 0.0)
+            note = (f"; sampled at {sample_shots} shot (M/E-step {per_me:.2f}s, of which support statistics {support_part:.2f}s, "
+                    f"linear in S) and scaled to {shots} shots")
+            per_me = per_me_zs + support_part * shots / sample_shots
+        total = len(mm_schedule) * per_me + mm_schedule[0] * mm_first + sum(mm_schedule[1:]) * mm_later
+        values.append(n_tasks / total)
+        texts.append(f"{sum(t_iter):.1f}s host time, MM loops {t_mm[0]:.2f}s / {t_mm[1]:.2f}s -> {1e3 * mm_first:.2f} / {1e3 * mm_later:.2f} ms per MM "
+                     f"iteration in the first / a later outer iteration, {per_me:.2f}s per M/E-step{note} -> {total:.0f}s per {n_tasks} tasks")
+    mean = sum(values) / len(values)
+    spread = (max(values) - min(values)) / mean if len(values) > 1 else None
+    return {"value": mean, "unit": "tasks/s", "cores": info["threads"], "kind": "port",
+            "samples": values, "rel_spread": spread, **host,
+            "sample": f"{n_tasks}-task batch of the same K={K}, 75-query workload, {len(values)} runs of 2 outer iterations with {ran} MM iterations each, "
+                      f"extrapolated over the recorded schedule ({mm_schedule[0]} + {int(sum(mm_schedule[1:]))} MM iterations in "
+                      f"{len(mm_schedule)} outer iterations, SURVEY.md 8d): " + " | ".join(f"run {i + 1}: {t}" for i, t in enumerate(texts)) +
+                      f"; mean {mean:.4g} tasks/s" + (f", relative spread {spread:.1%}" if spread is not None else "") +
+                      f"; {info['threads']} threads on {host['cpu_model']} ({host['cpus_usable']} of {host['cpus_online']} CPUs usable, "
+                      f"load average {host['loadavg_1min']:.1f} before the sample); torch {info['torch']} CPU eager",
             "extrapolated": True}
+
+
+def host_description(usable):
+    """What the cpu_baseline figure was measured on: the model string of the host's CPUs, how many of them this process may use
+    (sched_getaffinity) and how busy the host was with other work when the sample started."""
+    model = "unknown CPU"
+    try:
+        with open("/proc/cpuinfo") as f:
+            for line in f:
+                if line.lower().startswith("model name"):
+                    model = line.split(":", 1)[1].strip()
+                    break
+    except OSError:
+        pass
+    try:
+        load = os.getloadavg()[0]
+    except OSError:
+        load = float("nan")
+    return {"cpu_model": model, "cpus_online": os.cpu_count() or 1, "cpus_usable": usable, "loadavg_1min": load}
 
 
 def load_pmc():

@@ -27,8 +27,9 @@ extern "C" {
 
 /* 2: tclip_alpha_tim_run, tclip_laplacian_shot_run, tclip_match_clusters_host_strided, tclip_debug_set_mm_split added
  * 3: tclip_em_dirichlet_run_tasks (tclip_task_source) added
+ * 4: tclip_check_task_indices, tclip_profile_last_split_sorts added
  * (every entry point of an earlier version keeps its signature) */
-#define TCLIP_ABI_VERSION 3
+#define TCLIP_ABI_VERSION 4
 
 enum {
     TCLIP_OK = 0,
@@ -85,8 +86,8 @@ int tclip_em_dirichlet_run(const tclip_problem* p, const float* x_q, const float
  *   cols    device [B*N, K] i32 column permutation per task (applied to both tables), or NULL for the identity
  *   y_s     device [B*N, S] i64 support labels AFTER get_task's re-indexing (new label j = position of the old label in
  *           unique_labels), NULL iff S == 0
- * Index values are not checked on the device: the caller guarantees 0 <= idx < rows and 0 <= cols < K (the Python binding
- * checks them on the host, where the samplers produce them). */
+ * tclip_em_dirichlet_run_tasks itself does not know the tables' row counts and reads what the index tensors say: call
+ * tclip_check_task_indices on them first (the Python binding does, for host and device tensors alike). */
 typedef struct tclip_task_source {
     const float* table_q;
     const int64_t* q_idx;
@@ -97,6 +98,16 @@ typedef struct tclip_task_source {
 int tclip_em_dirichlet_run_tasks(const tclip_problem* p, const tclip_task_source* src, const int64_t* y_s,
                                  float* u, float* v, float* alpha, int32_t* preds, float* criterions,
                                  int32_t* mm_iters, void* workspace, size_t workspace_bytes, void* stream);
+
+/* Range check of DEVICE-resident index tensors before tclip_em_dirichlet_run_tasks / tclip_gather_rows - what torch's own
+ * `all_features_query[indices, :]` (src/eval_zero_shot.py:160-163, src/eval_few_shot.py:233-241) does by raising IndexError:
+ *   idx  device [n_idx]  i64, every value must lie in [0, n_rows)         (NULL with n_idx == 0: nothing to check)
+ *   cols device [n_cols] i32, every value must lie in [0, n_class)        (NULL with n_cols == 0)
+ * One pass over each on `stream`, then the call WAITS for the stream and returns TCLIP_ERR_ARG (text in tclip_last_error)
+ * when a value is out of range, TCLIP_OK otherwise.  Negligible next to the loop it protects (a few microseconds per
+ * million indices); keeps one int32 of device memory per calling thread. */
+int tclip_check_task_indices(const int64_t* idx, int64_t n_idx, int64_t n_rows, const int32_t* cols, int64_t n_cols,
+                             int32_t n_class, void* stream);
 
 /* Accuracy tail, device half: per task the clusters present in `preds` in first-appearance order
  * and the mean raw feature of each (compute_acc_clustering, em_dirichlet.py:61-71).

@@ -337,6 +337,30 @@ def test_table_fed_entry_equals_materialised_tensors(K, N, B, shots, perm, hard)
         assert torch.equal(getattr(ref, name), getattr(got, name)), name
     with pytest.raises(IndexError):
         engine.run_em_dirichlet_tasks(tq, q_idx + tab_q.shape[0], ts, s_idx, y_s, cols, **kw)
+    # (round 5) DEVICE-resident index tensors are range-checked too (tclip_check_task_indices): one bad entry raises, as
+    # torch's own `table[idx]` does - until round 4 it was an out-of-bounds read in k_gather_log_features / k_support_stats
+    q_dev = q_idx.to(DEV)
+    got_dev = engine.run_em_dirichlet_tasks(tq, q_dev, ts, s_idx.to(DEV) if shots else None, y_s, cols.to(DEV) if cols is not None else None, **kw)
+    assert torch.equal(got_dev.alpha, got.alpha) and torch.equal(got_dev.u, got.u)
+    bad = q_dev.clone()
+    bad[T - 1, 3] = tab_q.shape[0]
+    with pytest.raises(IndexError):
+        engine.run_em_dirichlet_tasks(tq, bad, ts, s_idx, y_s, cols, **kw)
+    bad[T - 1, 3] = -1
+    with pytest.raises(IndexError):
+        engine.run_em_dirichlet_tasks(tq, bad, ts, s_idx, y_s, cols, **kw)
+    if shots:
+        bad_s = s_idx.to(DEV).clone()
+        bad_s[0, 0] = tab_s.shape[0] + 5
+        with pytest.raises(IndexError):
+            engine.run_em_dirichlet_tasks(tq, q_dev, ts, bad_s, y_s, cols, **kw)
+    if cols is not None:
+        bad_c = cols.to(DEV).to(torch.int32).clone()
+        bad_c[0, 1] = K
+        with pytest.raises(IndexError):
+            engine.run_em_dirichlet_tasks(tq, q_dev, ts, s_idx, y_s, bad_c, **kw)
+    with pytest.raises(IndexError):
+        engine.gather_rows(tq, torch.tensor([0, tab_q.shape[0]], device=DEV))
 
 
 # ---------------------------------------------------------------------------------------------------------------------

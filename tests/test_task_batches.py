@@ -219,6 +219,15 @@ def _worker_eight(rank, world, port, out):
     except RuntimeError:
         shared_refused = True
     assert shared_refused
+    # two nodes of four GPUs each: device indices 0..3 repeat across the nodes and must be accepted (until round 5 the check
+    # compared bare indices over the whole world and refused every correct multi-node job)
+    assert sharding.check_one_device_per_rank(rank % 4, node_key=1000 + rank // 4) == [r % 4 for r in range(world)]
+    try:
+        sharding.check_one_device_per_rank(rank % 2, node_key=1000 + rank // 4)      # ... but not two ranks of ONE node on a device
+        shared_refused = False
+    except RuntimeError:
+        shared_refused = True
+    assert shared_refused
     if rank == 0:
         torch.save({"got": got, "secs": secs}, out)
     else:

@@ -611,6 +611,11 @@ constexpr int sure_registers() {
         return size_ilp * P > E ? E : size_ilp * P;
     }
     if (G == 64) return (TCLIP_G64_MIN_K >= 897 && E == 16) ? 12 : 0;      // 16 + e < K / 32 for K >= 897
+    // G = 32: one register per step of 32 elements; G = 16: two.  The instantiation E is launched for K > (next smaller
+    // size) x G, whose interleaved part has at least E - 4 registers' worth of steps for every E launch_mm_G hands out.
+    // G = 8 has FOUR registers per step and buckets (10 -> 13 -> 16) whose smallest row ends inside register E - 4
+    // (E = 13: K = 81 has size_ilp = 2, i.e. 8 sure registers, not 9): nothing is taken for sure there.
+    if (G == 8) return 0;
     return E > 4 ? E - 4 : 0;
 }
 // registers below it hold only slots inside the row in every lane (the split kernel queues them whole)
@@ -2400,6 +2405,19 @@ __global__ void k_gather_prototypes(const int32_t* __restrict__ preds, const flo
     }
 }
 
+
+// Range check of device-resident index tensors (tclip_check_task_indices): raises `bit` in *flag when some value lies
+// outside [0, limit) - what torch's own `table[idx]` turns into an IndexError (eval_zero_shot.py:160-163).
+template <typename I>
+__global__ void k_check_range(const I* __restrict__ v, size_t n, int64_t limit, int32_t* __restrict__ flag, int bit) {
+    bool bad = false;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+        const int64_t x = (int64_t)v[i];
+        bad = bad || x < 0 || x >= limit;
+    }
+    if (__any(bad) && (threadIdx.x & 63) == 0) atomicOr(flag, bit);
+}
+
 __global__ void k_gather_rows(const float* __restrict__ table, int64_t n_rows, int K, const int64_t* __restrict__ idx,
                               int64_t n_out, float* __restrict__ out) {
     const int64_t r = blockIdx.x;
@@ -2811,6 +2829,7 @@ static bool mm_has_split(int K) {
     const bool wide = g_rowset_min_rows == 0;
     int E;
     if (K >= TCLIP_G64_MIN_K && K >= 512 && !wide && TCLIP_G64_MIN_K > 0) E = 16;
+    else if (K <= TCLIP_G8_MAX_K && !wide) E = mm_regs_of((K + 7) / 8, 8);            // launch_mm's order of tests
     else if (K <= TCLIP_G16_MAX_K && !wide) E = mm_regs_of((K + 15) / 16, 16);
     else E = mm_regs_of((K + 31) / 32, 32);
     return E <= TCLIP_SPLIT_MAX_E && E >= TCLIP_SPLIT_MIN_E;
@@ -4027,6 +4046,31 @@ int tclip_cluster_prototypes(int32_t T, int32_t Q, int32_t K, const float* x_q, 
     hipLaunchKernelGGL(k_gather_prototypes, dim3(T), dim3(256), 0, st, preds, (const float*)dense, Q, K, Cmax, n_clusters,
                        cluster_ids, prototypes);
     TCLIP_HIP(hipGetLastError());
+    return TCLIP_OK;
+}
+
+int tclip_check_task_indices(const int64_t* idx, int64_t n_idx, int64_t n_rows, const int32_t* cols, int64_t n_cols,
+                             int32_t n_class, void* stream) {
+    if ((n_idx > 0 && !idx) || (n_cols > 0 && !cols) || n_idx < 0 || n_cols < 0 || n_rows < 1 || n_class < 1)
+        return fail(TCLIP_ERR_ARG, "bad argument to tclip_check_task_indices");
+    static thread_local int32_t* flag = nullptr;           // one word of device memory per calling thread, kept
+    static thread_local int flag_device = -1;
+    int dev = 0;
+    TCLIP_HIP(hipGetDevice(&dev));
+    if (flag && flag_device != dev) { (void)hipFree(flag); flag = nullptr; }
+    if (!flag) { TCLIP_HIP(hipMalloc((void**)&flag, sizeof(int32_t))); flag_device = dev; }
+    hipStream_t st = (hipStream_t)stream;
+    TCLIP_HIP(hipMemsetAsync(flag, 0, sizeof(int32_t), st));
+    if (n_idx > 0)
+        hipLaunchKernelGGL(k_check_range<int64_t>, dim3(ew_grid((size_t)n_idx)), dim3(256), 0, st, idx, (size_t)n_idx, (int64_t)n_rows, flag, 1);
+    if (n_cols > 0)
+        hipLaunchKernelGGL(k_check_range<int32_t>, dim3(ew_grid((size_t)n_cols)), dim3(256), 0, st, cols, (size_t)n_cols, (int64_t)n_class, flag, 2);
+    TCLIP_HIP(hipGetLastError());
+    int32_t h = 0;
+    TCLIP_HIP(hipMemcpyAsync(&h, flag, sizeof h, hipMemcpyDeviceToHost, st));
+    TCLIP_HIP(hipStreamSynchronize(st));
+    if (h & 1) return fail(TCLIP_ERR_ARG, "index out of range for the feature table");
+    if (h & 2) return fail(TCLIP_ERR_ARG, "column index out of range");
     return TCLIP_OK;
 }
 

@@ -62,6 +62,7 @@ _SIGNATURES = {
     "tclip_debug_set_kmeans_tile": (ctypes.c_int, [ctypes.c_int32]),
     "tclip_profile_last_kernels": (ctypes.c_int, [ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_double),
                                                   ctypes.POINTER(ctypes.c_int64), ctypes.POINTER(ctypes.c_int64)]),
+    "tclip_check_task_indices": (ctypes.c_int, [_P, ctypes.c_int64, ctypes.c_int64, _P, ctypes.c_int64, ctypes.c_int32, _P]),
     "tclip_profile_last_split_sorts": (ctypes.c_int, [ctypes.POINTER(ctypes.c_int64), ctypes.POINTER(ctypes.c_int64)]),
     "tclip_profile_collect": (ctypes.c_int, [ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_double),
                                              ctypes.POINTER(ctypes.c_int64), ctypes.POINTER(ctypes.c_int64)]),
@@ -91,7 +92,7 @@ def lib():
         for name, (res, args) in _SIGNATURES.items():
             fn = getattr(l, name)
             fn.restype, fn.argtypes = res, args
-        if l.tclip_abi_version() != 3:
+        if l.tclip_abi_version() != 4:
             raise RuntimeError("libtclip.so ABI version mismatch")
         _lib = l
     return _lib

@@ -93,13 +93,29 @@ def run_em_dirichlet(x_q, x_s=None, y_s=None, *, n_batches=1, iters, iter_mm=100
     return EMDirichletResult(u=u, v=v, alpha=alpha, preds=preds, criterions=crit, mm_iters=mm)
 
 
+def _check_on_device(idx, n_rows, cols, n_class, name):
+    """tclip_check_task_indices on device-resident tensors: IndexError where torch's own `table[idx]` would raise one"""
+    with torch.cuda.device(idx.device if idx is not None else cols.device):
+        rc = _capi.lib().tclip_check_task_indices(_ptr(idx) if idx is not None else None, idx.numel() if idx is not None else 0, max(1, int(n_rows)),
+                                                  _ptr(cols) if cols is not None else None, cols.numel() if cols is not None else 0, int(n_class), _stream())
+    if rc == 1:                             # TCLIP_ERR_ARG
+        raise IndexError(f"{name}: {_capi.lib().tclip_last_error().decode()}")
+    _capi.check(rc, "tclip_check_task_indices")
+
+
 def _index_tensor(idx, n_rows, dev, name):
-    """int64 (T,R) index tensor on the device; values are checked on the host when that is where they are (the samplers
-    produce CPU tensors), as torch's own `table[idx]` would raise on an index outside the table"""
+    """int64 (T,R) index tensor on the device, every value checked against the table's row count as torch's own
+    `table[idx]` checks it (IndexError): on the host when that is where the tensor is (the samplers produce CPU tensors),
+    by one pass on the device otherwise (tclip_check_task_indices)"""
     idx = idx.long()
-    if not idx.is_cuda and idx.numel() and (int(idx.min()) < 0 or int(idx.max()) >= n_rows):
-        raise IndexError(f"{name}: index out of range for a table of {n_rows} rows")
-    return idx.to(dev).contiguous()
+    if not idx.is_cuda:
+        if idx.numel() and (int(idx.min()) < 0 or int(idx.max()) >= n_rows):
+            raise IndexError(f"{name}: index out of range for a table of {n_rows} rows")
+        return idx.to(dev).contiguous()
+    idx = idx.to(dev).contiguous()
+    if idx.numel():
+        _check_on_device(idx, n_rows, None, 1, name)
+    return idx
 
 
 def run_em_dirichlet_tasks(table_q, q_idx, table_s=None, s_idx=None, y_s=None, cols=None, *, n_batches=1, iters, iter_mm=1000,
@@ -128,7 +144,10 @@ def run_em_dirichlet_tasks(table_q, q_idx, table_s=None, s_idx=None, y_s=None, c
         cols = cols.to(torch.int32)
         if tuple(cols.shape) != (T, K) or (not cols.is_cuda and (int(cols.min()) < 0 or int(cols.max()) >= K)):
             raise IndexError("cols must be (T,K) with values in [0, K)")
+        on_device = cols.is_cuda
         cols = cols.to(dev).contiguous()
+        if on_device:
+            _check_on_device(None, 1, cols, K, "cols")
     c = _Call(dev, _capi.Problem(n_batches, T // n_batches, Q, K, S, iters, iter_mm, int(lambd), int(bool(hard))), "tclip_workspace_bytes")
     u, v, alpha, preds = c.empty(T, Q, K), c.empty(T, K), c.empty(T, K, K), c.empty(T, Q, dtype=torch.int32)
     crit = torch.zeros(n_batches, max(iters, 1), device=dev)[:, :iters].contiguous()
@@ -322,7 +341,7 @@ def gather_rows(table, idx):
     """table (n,K) cuda f32, idx (m,) int64 -> (m,K) cuda f32 (device-side task construction)."""
     _require_cuda(table, "table")
     table = table.contiguous().float()
-    idx = idx.to(table.device).long().contiguous()
+    idx = _index_tensor(idx.reshape(-1), table.shape[0], table.device, "idx")
     out = torch.empty(idx.numel(), table.shape[1], device=table.device)
     with torch.cuda.device(table.device):
         rc = _capi.lib().tclip_gather_rows(_ptr(table), table.shape[0], table.shape[1], _ptr(idx), idx.numel(), _ptr(out), _stream())

@@ -127,11 +127,24 @@ def gather_rank_values(value, device=None):
     return [float(t.item()) for t in every]
 
 
-def check_one_device_per_rank(device_index, device=None):
-    """Every rank of a one-node job must drive its own GPU: gathers the ranks' device indices and raises when two ranks
-    share one (a launcher that did not export LOCAL_RANK, or a script that ignored it, would run N ranks on cuda:0 and
-    report N times the single-GPU rate as if it scaled).  Returns the list of indices."""
+def _node_key():
+    """a number that is the same for the ranks of one node and (practically) different across nodes: a hash of the host name
+    folded to 48 bits, exact in the float64 the ranks exchange"""
+    import hashlib
+    import socket
+    return float(int.from_bytes(hashlib.sha1(socket.gethostname().encode()).digest()[:6], "big"))
+
+
+def check_one_device_per_rank(device_index, device=None, node_key=None):
+    """Every rank must drive its own GPU: gathers the ranks' (node, device index) pairs and raises when two ranks OF ONE NODE
+    share a device (a launcher that did not export LOCAL_RANK, or a script that ignored it, would run N ranks on cuda:0 and
+    report N times the single-GPU rate as if it scaled).  Device indices repeat across the nodes of a multi-node job
+    (0..7 on each), so the node - a hash of its host name, `node_key` overrides it in tests - is part of the pair.
+    Returns the list of device indices by rank."""
     seen = [int(v) for v in gather_rank_values(float(device_index), device)]
-    if len(set(seen)) != len(seen):
-        raise RuntimeError(f"ranks share a GPU: device index per rank = {seen}")
+    nodes = [int(v) for v in gather_rank_values(_node_key() if node_key is None else float(node_key), device)]
+    pairs = list(zip(nodes, seen))
+    if len(set(pairs)) != len(pairs):
+        raise RuntimeError(f"ranks share a GPU: device index per rank = {seen}" +
+                           (f" (nodes {nodes})" if len(set(nodes)) > 1 else ""))
     return seen
