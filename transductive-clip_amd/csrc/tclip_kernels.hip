@@ -498,6 +498,31 @@ struct RowY {
             }
         }
     }
+    // every y of the lane at once (the split kernel's phase C, rows whose y is not kept in registers): the loads are issued
+    // together and waited for one by one, with nothing else of the memory pipe between them
+    __device__ __forceinline__ void fetch_all(float (&out)[E]) const {
+        if (!g) {                                   // a dead row (wave-uniform in the 64-lane layout, per lane group otherwise)
+#pragma unroll
+            for (int e = 0; e < E; e++) out[e] = -10.0f;
+            return;
+        }
+        if constexpr (G == 64) {
+            // one row per wavefront: its base is a scalar; a buffer descriptor over the row's K floats, one lane offset for all
+            // E loads (the register index is the instruction's immediate offset) and the hardware's own range check for the
+            // slots beyond the row (a read past num_records returns 0).  The asm keeps the loads in the iteration that uses
+            // them: hoisted out of the MM loop they are 16 registers that live across the dense passes again.
+            const float* base = g;                  // (the MM kernels make the row index of this layout a scalar: readfirstlane)
+            asm volatile("" : "+s"(base));
+            const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)base, 0, K * 4, 0x00020000);
+            int voff = elem_of<E, G>(0, lane) * 4;
+            asm volatile("" : "+v"(voff));  // (or the E sums voff + 128 e are loop invariants: sixteen registers instead of sixteen immediates)
+#pragma unroll
+            for (int e = 0; e < E; e++) out[e] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsrc, voff + e * 128, 0, 0));
+        } else {
+#pragma unroll
+            for (int e = 0; e < E; e++) out[e] = get(e);
+        }
+    }
     __device__ __forceinline__ float get(int e) const {
         if (kInRegs) return r[kInRegs ? e : 0];
         if (!g) return -10.0f;                       // dead rows: y is not read by lanes beyond the row either
@@ -534,6 +559,11 @@ __device__ __forceinline__ void mm_apply_updates(float (&beta)[E], const RowY<E,
                                                  const LogTabEntry* tab, const float* queue, int base, bool measure,
                                                  double& num, double& den) {
     const int n_full = full_registers<E, G>(K);    // registers below it hold only elements of the row (wave-uniform)
+    // y of rows that do not keep it in registers: fetched here, all at once (see split_apply_updates)
+    constexpr bool kYLocal = !RowY<E, G>::kInRegs;
+    float yl[kYLocal ? E : 1];
+    if constexpr (kYLocal) yv.fetch_all(yl);
+    auto y_of = [&](int e) { if constexpr (kYLocal) return yl[e]; else return yv.get(e); };
     // finishes pair p (the square root's table entries were requested one pair ago), stores and measures it
     auto finish = [&](int p, const PkUpdateStage& st) {
         const int e = 2 * p;
@@ -566,7 +596,7 @@ __device__ __forceinline__ void mm_apply_updates(float (&beta)[E], const RowY<E,
         const unsigned long long m1 = __builtin_amdgcn_ballot_w64(big1);
         const float lg1 = big1 ? queue[base + lanes_below(m1)] : 0.0f;
         base += __popcll(m1);
-        const PkUpdateStage st = pk_mm_update_stage1(a, f2{yv.get(e), yv.get(e + 1)}, pk(psi_s), f2{lg0, lg1}, tab);
+        const PkUpdateStage st = pk_mm_update_stage1(a, f2{y_of(e), y_of(e + 1)}, pk(psi_s), f2{lg0, lg1}, tab);
         if (p > 0) finish(p - 1, pending);         // while this pair's table look-ups are in flight
         pending = st;
     }
@@ -583,7 +613,7 @@ __device__ __forceinline__ void mm_apply_updates(float (&beta)[E], const RowY<E,
         float lg_small = lgamma_sleef_1_23_f64(big ? 2.0f : x1, sure);
         if (__builtin_expect(__builtin_amdgcn_ballot_w64(!sure) != 0ull, 0)) lg_small = sure ? lg_small : lgamma_sleef_05_23(big ? 2.0f : x1);
         const float psi1 = digamma_xp1(a, tab);
-        const float nb = mm_update_algebra(a, yv.get(e), psi_s, psi1, big ? lg_big : lg_small);
+        const float nb = mm_update_algebra(a, y_of(e), psi_s, psi1, big ? lg_big : lg_small);
         const bool ok = elem_of<E, G>(e, lane) < K;
         if (measure && ok) {
             const double df = (double)nb - (double)a;
@@ -921,6 +951,7 @@ __global__ __launch_bounds__(64 * W, (E > 16 ? TCLIP_MM_WAVES_LARGE : TCLIP_MM_W
         for (int r = 0; r < R; r++) {
             const int i = first + r * kGroups + group;
             row[r] = i < n ? a.rows[i] : 0;
+            if constexpr (G == 64) row[r] = __builtin_amdgcn_readfirstlane(row[r]);   // one row per wavefront: a scalar (RowY::fetch_all)
             const bool running = i < n && !a.stop[row[r] / a.rows_per_batch];
             const int have = (kDead && running) ? a.cache_len[row[r]] : 0;
             active[r] = running && (!kDead || have == a.chunk);
@@ -998,7 +1029,11 @@ __global__ __launch_bounds__(64 * W, (E > 16 ? TCLIP_MM_WAVES_LARGE : TCLIP_MM_W
                                    // 12 KB at 24 (12 wavefronts per CU, which is what those kernels' registers allow anyway)
 #endif
 #ifndef TCLIP_SPLIT_Y_REGS_MAX_E
-#define TCLIP_SPLIT_Y_REGS_MAX_E TCLIP_Y_REGS_MAX_E   // y of a row in registers up to this many registers per lane (else re-read from L1/L2 in phase C)
+#define TCLIP_SPLIT_Y_REGS_MAX_E 8     // y of a row in registers up to this many registers per lane; longer rows fetch it at the start of
+                                       // phase C (RowY::fetch_all).  Round 4 kept 16 registers of y across the dense passes: the compiler
+                                       // spilled them and re-read a pair at a time inside phase C, each re-read followed by a wait for
+                                       // everything in flight.  Same-box A/B (profiles/r05_ab_phase_c.txt): K = 1000 -1.1 %, few-shot
+                                       // K = 1000 -1.2 %, K = 397 hard -0.9 % per engine call, bit-identical; VGPR spills 59 -> 22
 #endif
 #ifndef TCLIP_SPLIT_WAVES_SMALL
 #define TCLIP_SPLIT_WAVES_SMALL 4  // wavefronts per SIMD requested for up to 8 registers per lane
@@ -1022,10 +1057,20 @@ __device__ __forceinline__ float lgamma_gt7_dense(float v) {
 
 // phase C of the split iteration: entry `slot` of the wavefront's planes holds lgamma(a+1) and digamma(a+1)
 // kTiny: some parameter of the wavefront's rows may be 1e-11 or less (see pk_mm_update_stage1_core)
-template <int E, int G, bool kTiny>
+// kMeasure: the stop test's iteration (a template parameter so that the other 49 of 50 iterations are ONE basic block per
+// register-pair loop: with the flag tested per pair the scheduler could not overlap one pair's chain with the next one's)
+template <int E, int G, bool kTiny, bool kMeasure>
 __device__ __forceinline__ void split_apply_updates(float (&beta)[E], const RowY<E, G, TCLIP_SPLIT_Y_REGS_MAX_E>& yv, int K, int lane, float psi_s,
                                                     const float* my0, const float* my1, const uint32_t (&slot)[(E + 1) / 2],
-                                                    bool measure, double& num, double& den) {
+                                                    double& num, double& den) {
+    constexpr bool measure = kMeasure;
+    // y of the row: from the registers of the whole chunk (short rows), or fetched here, all at once, for this phase alone -
+    // 16 values per lane that live across the dense passes were 16 values the compiler spilled and re-read one pair at a
+    // time, each re-read followed by a wait for EVERYTHING in flight, the next pair's square-root table entries included
+    constexpr bool kYLocal = !RowY<E, G, TCLIP_SPLIT_Y_REGS_MAX_E>::kInRegs;
+    float yl[kYLocal ? E : 1];
+    if constexpr (kYLocal) yv.fetch_all(yl);
+    auto y_of = [&](int e) { if constexpr (kYLocal) return yl[e]; else return yv.get(e); };
     const int n_full = full_registers<E, G>(K);
     auto finish = [&](int p, const PkUpdateStage& st) {
         const int e = 2 * p;
@@ -1052,7 +1097,7 @@ __device__ __forceinline__ void split_apply_updates(float (&beta)[E], const RowY
         const int e = 2 * p;
         const f2 a{beta[e], beta[e + 1]};
         const int i0 = (int)(slot[p] & 0xffffu), i1 = (int)(slot[p] >> 16);
-        const PkUpdateStage st = pk_mm_update_stage1_given<kTiny>(a, f2{yv.get(e), yv.get(e + 1)}, psi_s, my1[i0], my1[i1], my0[i0], my0[i1]);
+        const PkUpdateStage st = pk_mm_update_stage1_given<kTiny>(a, f2{y_of(e), y_of(e + 1)}, psi_s, my1[i0], my1[i1], my0[i0], my0[i1]);
         if (p > 0) finish(p - 1, pending);
         pending = st;
     }
@@ -1061,7 +1106,7 @@ __device__ __forceinline__ void split_apply_updates(float (&beta)[E], const RowY
         constexpr int e = E - 1;
         const float a = beta[e];
         const int i = (int)(slot[e >> 1] & 0xffffu);
-        const float nb = mm_update_algebra(a, yv.get(e), psi_s, my1[i], my0[i]);
+        const float nb = mm_update_algebra(a, y_of(e), psi_s, my1[i], my0[i]);
         const bool ok = elem_of<E, G>(e, lane) < K;
         if (measure && ok) {
             const double df = (double)nb - (double)a;
@@ -1363,8 +1408,11 @@ __device__ __forceinline__ void mm_iterate_wave_split(float (&beta)[E], const Ro
     pl.valid = true;
     // phase C
     wave_lds_handoff();
-    if (__builtin_expect(tiny, 0)) split_apply_updates<E, G, true>(beta, yv, K, lane, psi_s, my0, my1, pl.slot, measure, num, den);
-    else split_apply_updates<E, G, false>(beta, yv, K, lane, psi_s, my0, my1, pl.slot, measure, num, den);
+    if (__builtin_expect(measure, 0)) {
+        if (tiny) split_apply_updates<E, G, true, true>(beta, yv, K, lane, psi_s, my0, my1, pl.slot, num, den);
+        else split_apply_updates<E, G, false, true>(beta, yv, K, lane, psi_s, my0, my1, pl.slot, num, den);
+    } else if (__builtin_expect(tiny, 0)) split_apply_updates<E, G, true, false>(beta, yv, K, lane, psi_s, my0, my1, pl.slot, num, den);
+    else split_apply_updates<E, G, false, false>(beta, yv, K, lane, psi_s, my0, my1, pl.slot, num, den);
     wave_lds_handoff();
     TCLIP_CLK(5, tclk);
 }
@@ -1383,7 +1431,8 @@ __global__ __launch_bounds__(64, (E > 16 ? TCLIP_MM_WAVES_LARGE : (E > 8 ? TCLIP
     const int K = KC > 0 ? KC : a.K;
     for (int first = blockIdx.x * kRows; first < n; first += gridDim.x * kRows) {
         const int i = first + group;
-        const int row = i < n ? a.rows[i] : 0;
+        int row = i < n ? a.rows[i] : 0;
+        if constexpr (G == 64) row = __builtin_amdgcn_readfirstlane(row);     // one row per wavefront: its y pointer is a scalar register pair
         const bool active = i < n && !a.stop[row / a.rows_per_batch];
         if (!__any(active)) continue;
         float beta[E];

@@ -254,11 +254,22 @@ __device__ __forceinline__ f2 pk_t_of(f2 lg1, f2 m) { return m - lg1; }
 // +-inf or nan); the zero test is wave-uniform and per pair: min(|deno.x|, |deno.y|) == 0.  (Until round 5 it tested the
 // PRODUCT of the two, which a NaN partner hides: the slot beyond the row of a ragged register pair holds a = 0, whose
 // curvature without the small-parameter select is (|t| + |t|) / 0 = NaN.  v_min_f32 returns the other operand for a NaN.)
+#ifndef TCLIP_QUOTIENT_FIXUP
+#define TCLIP_QUOTIENT_FIXUP 1
+#endif
 __device__ __forceinline__ f2 pk_update_quotient(f2 nume, f2 deno) {
     f2 q = pk_div_rn(nume, deno);
+#if TCLIP_QUOTIENT_FIXUP
+    // v_div_fixup_f32 is the hardware's own table of IEEE division's special cases (x / 0 = +-inf, 0 / 0 = NaN, ...) and hands the
+    // quotient through otherwise: one instruction per component and NO branch - the wave-uniform test it replaces ended a basic
+    // block per register pair, so the scheduler could not move one pair's table look-ups, LDS reads or divisions under
+    // another pair's dependent chain (round 5)
+    return f2{__builtin_amdgcn_div_fixupf(q.x, deno.x, nume.x), __builtin_amdgcn_div_fixupf(q.y, deno.y, nume.y)};
+#else
     if (__builtin_expect(__builtin_amdgcn_ballot_w64(__builtin_fminf(__builtin_fabsf(deno.x), __builtin_fabsf(deno.y)) == 0.0f) != 0ull, 0))
         q = pk_sel(deno == pk(0.0f), nume * pk(__builtin_inff()), q);
     return q;
+#endif
 }
 
 // One MM update of two parameters (see mm_update_algebra) in two stages, so that a caller can put other work (the next pair's digamma) between the
