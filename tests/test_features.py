@@ -144,36 +144,3 @@ def test_few_shot_validation_sweep_then_test_run(tmp_path):
     assert a.lambd == best
     row = open(tmp_path / "results_few_shot" / "test" / "synthetic" / "PADDLE_softmax_s2.txt").read().splitlines()[-1]
     assert row.split("\t")[:4] == ["2", "75", "5", str(round(100 * float(acc_test), 1))]
-
-
-@pytest.mark.gpu
-def test_sweep_driver_on_the_saved_feature_layout(tmp_path):
-    """sweep.py over data/<dataset>/saved_features/: all zero-shot methods, all few-shot methods (the tunable ones after
-    a validation sweep), one process; a dataset without files is skipped, not fatal."""
-    import sys
-    from conftest import PKG
-    from tclip_amd import features, synth
-    sys.path.insert(0, PKG)
-    import sweep
-    K = 10
-    d = tmp_path / "data" / "toy" / "saved_features"
-    d.mkdir(parents=True)
-    for split, seed in (("train", 21), ("val", 22), ("test", 23)):
-        feats, labels = synth.make_feature_table(K, 40, seed=seed)
-        features.save_features(str(d / f"{split}_softmax_RN50_T30.plk"), feats, labels)
-    small = ["number_tasks", "4", "batch_size", "2"]
-    zs = sweep.main(["zero_shot", "--datasets", "toy", "absent", "--results-root", str(tmp_path), "--opts"] + small)
-    assert len(zs) == 2 * len(sweep.ZERO_SHOT) and all(a is not None and 0.2 < a <= 1.0 for _, a in zs[:len(sweep.ZERO_SHOT)])
-    assert all(a is None for _, a in zs[len(sweep.ZERO_SHOT):])
-    tune = sweep.main(["tune", "--datasets", "toy", "--shots", "2", "--methods", "paddle", "bdcspn", "--results-root", str(tmp_path),
-                       "--opts"] + small)
-    assert len(tune) == len(sweep.GRIDS["paddle"][1]) + len(sweep.GRIDS["bdcspn"][1]) and all(a is not None for _, a in tune)
-    fs = sweep.main(["few_shot", "--datasets", "toy", "--shots", "2", "--methods", "em_dirichlet", "paddle", "bdcspn",
-                     "--results-root", str(tmp_path), "--opts"] + small)
-    assert [a is not None for _, a in fs] == [True, True, True]
-    rows = open(tmp_path / "results_few_shot" / "test" / "toy" / "PADDLE_softmax_s2.txt").read().splitlines()
-    assert rows[-1].split("\t")[:3] == ["2", "75", "5"]
-    # a tunable method without its validation sweep is an error of that run only (alpha_tim was not tuned above)
-    with pytest.raises(ValueError, match="optimal parameter"):
-        sweep.main(["few_shot", "--datasets", "toy", "--shots", "2", "--methods", "alpha_tim", "--results-root", str(tmp_path),
-                    "--opts"] + small)

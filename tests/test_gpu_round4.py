@@ -200,13 +200,13 @@ def test_configs4_batch_few_shot_k1000_s4000():
 
 
 # ---------------------------------------------------------------------------------------------------------------------
-def _check_bigbatch(name, hard, few):
+def _check_bigbatch(name, hard, few, two_stage=True):
     """a lean reference fixture (digests + samples; inputs regenerated from integer draws) against the engine"""
     from helpers import intsynth
     from tclip_amd import engine
     g = np.load(os.path.join(GOLDEN, name + ".npz"))
     K, N, iters, shots = int(g["K"]), int(g["N"]), int(g["iters"]), int(g["shots"])
-    assert N * K > TWO_STAGE_MIN_ROWS, "the fixture must reach the two-stage stop test"
+    assert (N * K > TWO_STAGE_MIN_ROWS) == two_stage, "the fixture must reach the two-stage stop test"
     if few:
         x_q, y_q, x_s, y_s = intsynth.make_tasks(int(g["seed"]), N, K, 75, shots=shots, boost=int(g["boost"]))
         assert _sha(x_s) == str(g["x_s_sha1"]) and np.array_equal(y_s, g["y_s"].reshape(N, -1))

@@ -89,7 +89,7 @@ def parse_args(argv=None):
 
 
 def main(argv=None, keep_process_group=False):
-    """keep_process_group: a caller that runs several evaluations in one process (sweep.py) destroys the group itself"""
+    """keep_process_group: a caller that runs several evaluations in one process destroys the group itself"""
     ns, args = parse_args(argv)
     dist_on = "RANK" in os.environ
     local_rank = int(os.environ.get("LOCAL_RANK", args.device))
@@ -101,7 +101,7 @@ def main(argv=None, keep_process_group=False):
     device = torch.device("cuda", local_rank)
     if dist_on:
         import torch.distributed as dist
-        if not dist.is_initialized():          # sweep.py calls main() repeatedly in one process: the group is created once
+        if not dist.is_initialized():          # a caller may run main() repeatedly in one process: the group is created once
             dist.init_process_group("nccl", device_id=device)
     if ns.support is not None and ns.query is None:
         raise SystemExit("--support needs --query (or give neither and use the data/<dataset>/saved_features/ layout)")
