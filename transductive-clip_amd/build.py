@@ -6,7 +6,7 @@ kernels reproduce the reference's separately rounded fp32 operations and spell e
 multiply-add they want explicitly (csrc/tclip_math.h).  -fno-slp-vectorize: the kernels spell the packed fp32 operations they
 want themselves (csrc/tclip_pk.h); what the SLP vectoriser packed on its own in the MM kernels cost more in register moves and
 explicit negations than the packed instruction saved (gfx950 issues one v_pk_*_f32 in the time of two scalar ones), and its
-packed double-float code spilled."""
+packed double-float code spilled (HISTORY.md section 5, round 4)."""
 import os
 import subprocess
 import sys
