@@ -38,10 +38,9 @@ def test_headline_kernel_combination_matches_reference_k1000_n17():
     kernels that ran are the headline's."""
     from helpers import intsynth
     from tclip_amd import engine
-    if not os.path.exists(os.path.join(GOLDEN, "bigbatch_zs_soft_K1000_N17.npz")):
-        pytest.skip("fixture not generated yet (tests/golden/make_golden.py --large bigbatch_zs_soft_K1000_N17: ~2 h of reference time)")
     g = _check_bigbatch("bigbatch_zs_soft_K1000_N17", hard=False, few=False)
     assert int(g["K"]) == 1000 and int(g["N"]) == 17 and int(g["iters"]) == 20
+    assert g["mm_iters"].tolist() == [101] + [1000] * 19           # an early stop decided by the two-stage sum, then 19 x 19 decisions not to
     x_q, _ = intsynth.make_tasks(int(g["seed"]), 17, 1000, 75, boost=int(g["boost"]))
     x = torch.from_numpy(x_q).to(DEV)
     names = _kernels_of(lambda: engine.run_em_dirichlet(x, n_batches=1, iters=2, iter_mm=120, lambd=200 * 75))
