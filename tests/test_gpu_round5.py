@@ -50,8 +50,7 @@ def test_headline_kernel_combination_matches_reference_k1000_n17():
 
 def test_few_shot_k1000_four_shots_matches_reference():
     """one task, K = 1000, S = 4000 support rows (configs[4]'s support size) against the reference's own run"""
-    if not os.path.exists(os.path.join(GOLDEN, "fs_soft_K1000_N1_s4.npz")):
-        pytest.skip("fixture not generated yet (tests/golden/make_golden.py --large fs_soft_K1000_N1_s4)")
     g = _check_bigbatch("fs_soft_K1000_N1_s4", hard=False, few=True, two_stage=False)
     assert int(g["K"]) == 1000 and int(g["shots"]) == 4
+    assert g["mm_iters"].tolist() == [151, 151] + [51] * 18                 # an early stop in EVERY outer iteration
     assert np.array_equal(np.asarray(g["u"]).shape, (1, 75, 1000))
