@@ -21,7 +21,7 @@ def golden_names(prefix=""):
     """method-level fixtures (the eval_* files pin the task-batch loop and have another schema)"""
     return sorted(f[:-4] for f in os.listdir(GOLDEN)
                   if f.endswith(".npz") and f.startswith(prefix) and not f.startswith("eval_")
-                  and (prefix or not f.startswith("bigbatch_"))        # lean schema: digests + samples, inputs regenerated
+                  and (prefix or not f.startswith(("bigbatch_", "lean_")))        # lean schema: digests + samples, inputs regenerated
                   and (prefix or not any(m in f for m in ("_skm_", "_hkm_", "_paddle_", "_emg_", "_klk_", "_emgc_", "_bdcspn_", "_tim_", "_lshot_"))))
 
 

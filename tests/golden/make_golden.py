@@ -165,10 +165,10 @@ LARGE = {
     "bigbatch_zs_soft_K1000_N17": ("zs_soft", 1000, 17, 20, 0, 2083, False),
     # (round 5) configs[4]'s support size: ONE task at K = 1000 with 4 shots, S = 4000 support rows.  The reference's
     # (1,S,K,K) temporary is 16 GB (few_shot/em_dirichlet.py:196-200), once per outer iteration.
-    "fs_soft_K1000_N1_s4": ("fs_soft", 1000, 1, 20, 4, 2084, False),
+    "lean_fs_soft_K1000_N1_s4": ("fs_soft", 1000, 1, 20, 4, 2084, False),
 }
 INTSYNTH_LEAN = {"bigbatch_zs_soft_K100_N170", "bigbatch_zs_hard_K397_N42", "bigbatch_fs_soft_K100_N170_s1",
-                 "bigbatch_zs_soft_K1000_N17", "fs_soft_K1000_N1_s4"}
+                 "bigbatch_zs_soft_K1000_N17", "lean_fs_soft_K1000_N1_s4"}
 LEAN_BOOST = 64          # soft rows: the first outer iteration of the 170-task batch stops at MM iteration 151 (boost 4096: never)
 
 

@@ -5,7 +5,7 @@
   k_mm_split<16,64,1000> (the rest) and the two-stage stop test k_mm_decide_partial - the exact kernel combination every
   batch of the K = 1000 headline runs.  Until round 4 that combination was compared with the C++ oracle only (which shares
   csrc/tclip_math.h with the product); the reference's own K = 1000 fixtures had 1 and 3 tasks (single-stage stop test).
-* `fs_soft_K1000_N1_s4` - ONE few-shot task at K = 1000 with 4 shots, S = 4000 support rows: configs[4]'s support size, where
+* `lean_fs_soft_K1000_N1_s4` - ONE few-shot task at K = 1000 with 4 shots, S = 4000 support rows: configs[4]'s support size, where
   the reference's (1,S,K,K) temporary is 16 GB.  K = 1000 few-shot had been pinned to the reference at 1 shot only.
 (`eval_zs_soft_K100`, the evaluator fixture at a BASELINE class count, is a case of
 tests/test_gpu_engine_properties.py::test_task_batch_loop_matches_reference.)
@@ -50,7 +50,7 @@ def test_headline_kernel_combination_matches_reference_k1000_n17():
 
 def test_few_shot_k1000_four_shots_matches_reference():
     """one task, K = 1000, S = 4000 support rows (configs[4]'s support size) against the reference's own run"""
-    g = _check_bigbatch("fs_soft_K1000_N1_s4", hard=False, few=True, two_stage=False)
+    g = _check_bigbatch("lean_fs_soft_K1000_N1_s4", hard=False, few=True, two_stage=False)
     assert int(g["K"]) == 1000 and int(g["shots"]) == 4
     assert g["mm_iters"].tolist() == [151, 151] + [51] * 18                 # an early stop in EVERY outer iteration
     assert np.array_equal(np.asarray(g["u"]).shape, (1, 75, 1000))
