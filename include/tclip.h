@@ -27,7 +27,7 @@ extern "C" {
 
 /* 2: tclip_alpha_tim_run, tclip_laplacian_shot_run, tclip_match_clusters_host_strided, tclip_debug_set_mm_split added
  * 3: tclip_em_dirichlet_run_tasks (tclip_task_source) added
- * 4: tclip_check_task_indices, tclip_profile_last_split_sorts added
+ * 4: tclip_check_task_indices, tclip_profile_last_split_sorts, tclip_debug_set_split_keep_placement added
  * (every entry point of an earlier version keeps its signature) */
 #define TCLIP_ABI_VERSION 4
 
@@ -290,6 +290,10 @@ int tclip_profile_last_kernels(double* busy_ms, double* launch_ms_sum, int64_t* 
  * sorts anew only when an element has left its class: the wavefront-iterations the kernel ran in the window of the LAST
  * tclip_profile_collect of this thread, and how many of them ran the full placement (the first of every launch does). */
 int tclip_profile_last_split_sorts(int64_t* wave_iterations, int64_t* sorts);
+/* Test hook: 0 makes k_mm_split sort its class queues in every MM iteration (what rounds 3-4 did), non-zero restores the default
+ * (the placement of an iteration is kept for the next one and checked by the dense passes).  Process-wide; results do not
+ * depend on it (tests/test_gpu_round5.py::test_kept_placement_is_invisible). */
+int tclip_debug_set_split_keep_placement(int32_t on);
 
 /* Dead rows are spared the rest of their schedule once a limit-cycle probe (run after each of the
  * first `chunks` 50-iteration chunks) finds them on a cycle of the fp32 map - an exact shortcut.

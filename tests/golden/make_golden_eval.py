@@ -78,6 +78,9 @@ def main():
     if "K100" in only:
         only.discard("K100")
         cases = [("zs", False, None, big)]
+    if "K100more" in only:          # few-shot soft and zero-shot hard at the same class count and batch size
+        only.discard("K100more")
+        cases = [("fs", False, None, big), ("zs", True, None, big)]
     for case in cases:
         kind, hard, other = case[:3]
         shape = case[3] if len(case) > 3 else {"K": 10, "number_tasks": 20, "batch_size": 10}
@@ -128,7 +131,19 @@ def main():
             oq = record_iter(ef.SamplerQuery_few_shot, q)
             os_ = record_iter(ef.SamplerSupport_few_shot, s)
             ev = ef.Evaluator_few_shot(device=torch.device("cpu"), args=args, log_file="/tmp/golden_eval.log")
-            acc, t = ev.evaluate_tasks(model, feats_s, labels_s, feats, labels)
+            per_task = []
+            real_ci = ef.compute_confidence_interval
+
+            def recording_ci(data, *a, **k):
+                per_task.append(np.asarray(data, np.float32).copy())
+                return real_ci(data, *a, **k)
+            ef.compute_confidence_interval = recording_ci
+            try:
+                acc, t = ev.evaluate_tasks(model, feats_s, labels_s, feats, labels)
+            finally:
+                ef.compute_confidence_interval = real_ci
+            if K > 10:
+                out["task_accuracy"] = np.stack(per_task)        # (batches, batch_size)
             ef.SamplerQuery_few_shot.__iter__ = oq
             ef.SamplerSupport_few_shot.__iter__ = os_
             out["query_idx"] = torch.stack(q).numpy().reshape(n_tasks // bs, bs, 75)

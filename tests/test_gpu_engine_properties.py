@@ -251,13 +251,13 @@ def test_bench_scale_call_equals_its_batches_run_alone():
 @pytest.mark.parametrize("name", ["eval_zs_soft_K10", "eval_zs_hard_K10", "eval_fs_soft_K10", "eval_fs_hard_K10", "eval_zs_soft_kmeans_K10",
                                   "eval_zs_hard_kmeans_K10", "eval_zs_em_gaussian_K10", "eval_zs_em_gaussian_cov_K10", "eval_zs_kl_kmeans_K10", "eval_zs_clip_K10",
                                   "eval_fs_paddle_K10", "eval_fs_bdcspn_K10", "eval_fs_alpha_tim_K10", "eval_fs_laplacian_shot_K10",
-                                  "eval_zs_soft_K100"])
+                                  "eval_zs_soft_K100", "eval_zs_hard_K100", "eval_fs_soft_K100"])
 def test_task_batch_loop_matches_reference(name):
     """evaluate_tasks on the seeded synthetic table: the reference's mean accuracy (fixtures made
     by running the reference's Evaluator_*.evaluate_tasks), for every method behind the boundary.
-    eval_zs_soft_K100 (round 5) is the loop at a BASELINE class count - configs[1]'s shape, K = 100 with batch_size = 100, two
-    batches - and also holds every task's accuracy as the reference handed it to compute_confidence_interval
-    (eval_zero_shot.py:176)."""
+    eval_{zs_soft,zs_hard,fs_soft}_K100 (round 5) are the loops at a BASELINE class count - configs[1]'s shape, K = 100 with
+    batch_size = 100, two batches - and also hold every task's accuracy as the reference handed it to
+    compute_confidence_interval (eval_zero_shot.py:176, eval_few_shot.py:258)."""
     from src.utils import CfgNode
     from tclip_amd import synth
     g = np.load(os.path.join(GOLDEN, name + ".npz"))
@@ -287,7 +287,10 @@ def test_task_batch_loop_matches_reference(name):
     else:
         from src.eval_few_shot import Evaluator_few_shot
         fs, ls = synth.make_feature_table(K, int(g["support_rows_per_class"]), seed=int(g["seed"]) + 1)
-        acc, t = Evaluator_few_shot(torch.device("cuda:0"), a, None).evaluate_tasks(None, fs, ls, feats, labels)
+        ev = Evaluator_few_shot(torch.device("cuda:0"), a, None)
+        acc, t = ev.evaluate_tasks(None, fs, ls, feats, labels)
+        if "task_accuracy" in g.files:
+            assert np.array_equal(np.asarray(ev.last_task_accuracies, np.float32).reshape(g["task_accuracy"].shape), g["task_accuracy"])
     assert abs(float(acc) - float(g["mean_accuracy"])) < tol
     assert t > 0 or method == "CLIP"        # the reference logs a zero time for the inductive baseline
 

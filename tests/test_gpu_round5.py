@@ -54,3 +54,41 @@ def test_few_shot_k1000_four_shots_matches_reference():
     assert int(g["K"]) == 1000 and int(g["shots"]) == 4
     assert g["mm_iters"].tolist() == [151, 151] + [51] * 18                 # an early stop in EVERY outer iteration
     assert np.array_equal(np.asarray(g["u"]).shape, (1, 75, 1000))
+
+
+@pytest.mark.parametrize("K,B,N,hard,shots", [(100, 2, 30, False, 0), (397, 1, 20, True, 0), (1000, 1, 6, False, 0), (1000, 1, 3, False, 1),
+                                             (80, 2, 25, False, 2), (300, 1, 12, True, 0), (640, 1, 8, False, 0)])
+def test_kept_placement_is_invisible(K, B, N, hard, shots):
+    """k_mm_split keeps the placement of its elements in the three class queues from one MM iteration to the next and sorts anew
+    only when a dense pass meets an entry that has left its class (round 5).  With the hook that makes it sort in EVERY iteration
+    (what rounds 3-4 did) the results must be the same bits - 16-, 32- and 64-lane layouts, fixed-K and run-time-K kernels, soft /
+    hard, zero- / few-shot - and the counters must show the mechanism at work: every iteration sorts with the hook, a small
+    fraction without (the first iteration of every launch always does)."""
+    from tclip_amd import _capi, engine, synth
+    T = B * N
+    x_q, _ = synth.make_query_tasks(T, K, seed=500 + K, k_eff=(5 if shots else None))
+    x = x_q.to(DEV)
+    xs = ys = None
+    if shots:
+        x_s, y_s = synth.make_support(T, K, shots, seed=501 + K)
+        xs, ys = x_s.to(DEV), y_s.squeeze(2).to(DEV)
+    kw = dict(n_batches=B, iters=4, iter_mm=230, lambd=max(1, int(K / 5)) * 75, hard=hard)
+    out, counts = {}, {}
+    try:
+        for keep in (1, 0):
+            _capi.check(_capi.lib().tclip_debug_set_split_keep_placement(keep), "tclip_debug_set_split_keep_placement")
+            engine.profile_enable(True)
+            engine.profile_collect()
+            out[keep] = engine.run_em_dirichlet(x, xs, ys, **kw)
+            engine.profile_collect()
+            counts[keep] = engine.profile_last_split_sorts()
+            engine.profile_enable(False)
+    finally:
+        _capi.lib().tclip_debug_set_split_keep_placement(1)
+        engine.profile_enable(False)
+    for name in ("alpha", "u", "v", "preds", "mm_iters", "criterions"):
+        assert torch.equal(getattr(out[1], name), getattr(out[0], name)), name
+    (it1, so1), (it0, so0) = counts[1], counts[0]
+    assert it1 == it0 > 0, "k_mm_split did not run: the test would prove nothing"
+    assert so0 == it0, "with the hook every wavefront-iteration sorts"
+    assert 0 < so1 < 0.5 * it1, f"the kept placement is not kept: {so1} sorts in {it1} wavefront-iterations"

@@ -451,6 +451,8 @@ struct MMArgs {
     int32_t* next_rows;
     int32_t* next_count;
     int K, rows_per_batch, chunk, l0, l1, has_check, n_checks;
+    int keep_placement;     // k_mm_split: 1 = keep the class queues' placement across the iterations of a launch (the default),
+                            // 0 = sort in every iteration as rounds 3-4 did (tclip_debug_set_split_keep_placement: same bits)
 };
 
 // One MM iteration of a row held in registers, in place.  If `measure`, also accumulates this
@@ -1245,7 +1247,7 @@ __device__ __forceinline__ void split_scatter(const float (&beta)[E], int K, int
 template <int E, int G, int KC = 0>
 __device__ __forceinline__ void mm_iterate_wave_split(float (&beta)[E], const RowY<E, G, TCLIP_SPLIT_Y_REGS_MAX_E>& yv, int K, int lane, bool active,
                                                       const LogTabEntry* tab, float* my0, float* my1, bool measure,
-                                                      double& num, double& den, SplitPlacement<E>& pl) {
+                                                      double& num, double& den, SplitPlacement<E>& pl, bool keep_placement) {
     const int lane64 = threadIdx.x & 63;
 #ifdef TCLIP_PHASE_CLOCK
     long long tclk = __builtin_readcyclecounter();
@@ -1296,7 +1298,7 @@ __device__ __forceinline__ void mm_iterate_wave_split(float (&beta)[E], const Ro
     const bool tiny = __builtin_amdgcn_ballot_w64(smallest <= (int32_t)0x2d2febffu) != 0ull;      // 0x2d2febff = 1e-11f
     const float psi_s = digamma_pos_f32(s, tab);                    // the row sums of the wavefront's rows, one evaluation
     // phase A + phase B, until the dense passes have met every entry in a queue whose form is the one for its value
-    bool sort_now = !(TCLIP_SPLIT_LAZY && pl.valid);
+    bool sort_now = !(TCLIP_SPLIT_LAZY && keep_placement && pl.valid);
     TCLIP_CLK(0, tclk);
     for (;;) {
         if (sort_now) {
@@ -1451,7 +1453,8 @@ __global__ __launch_bounds__(64, (E > 16 ? TCLIP_MM_WAVES_LARGE : (E > 8 ? TCLIP
         for (int i = 0; i < 8; i++) pl.clk[i] = 0;
 #endif
         for (int l = a.l0; l <= a.l1; l++)
-            mm_iterate_wave_split<E, G, KC>(beta, yv, K, lane, active, tab, plane0, plane1, a.has_check && l == a.l1, num, den, pl);
+            mm_iterate_wave_split<E, G, KC>(beta, yv, K, lane, active, tab, plane0, plane1, a.has_check && l == a.l1, num, den, pl,
+                                            a.keep_placement != 0);
         if (!active) continue;
 #pragma unroll
         for (int e = 0; e < E; e++) {
@@ -2717,6 +2720,7 @@ thread_local Profile g_prof;
 static int g_probe_chunks = TCLIP_PROBE_CHUNKS;     // tclip_debug_set_probe_chunks
 static int g_rowset_min_rows = -1;                  // tclip_debug_set_rowset_min_rows; negative: the default rule
 static int g_mm_split = -1;                         // tclip_debug_set_mm_split: 0 never, 1 always, negative: from the second outer iteration on
+static int g_split_keep_placement = 1;              // tclip_debug_set_split_keep_placement: 0 = k_mm_split sorts its queues in every iteration
 
 static hipEvent_t prof_event() {
     if (g_prof.used == g_prof.ev.size()) {
@@ -3291,6 +3295,7 @@ static int enqueue_batches(const tclip_problem& p, const RowSrc& q_src, const Ro
             a.cache = cache; a.rowpart = rowpart; a.rows = mm_rows; a.n_rows = counts; a.stop = stop;
             a.next_rows = nullptr; a.next_count = nullptr;
             a.K = K; a.rows_per_batch = N * K; a.chunk = c;
+            a.keep_placement = g_split_keep_placement;
             a.l0 = c == 0 ? 0 : 50 * c + 1;
             a.l1 = 50 * (c + 1) < p.iter_mm - 1 ? 50 * (c + 1) : p.iter_mm - 1;
             a.has_check = (a.l1 > 0 && a.l1 % 50 == 0) ? 1 : 0;
@@ -3954,6 +3959,11 @@ int tclip_debug_set_fixed_k_kernels(int32_t on) {
 
 int tclip_debug_set_mm_split(int32_t mode) {
     g_mm_split = mode;
+    return TCLIP_OK;
+}
+
+int tclip_debug_set_split_keep_placement(int32_t on) {
+    g_split_keep_placement = on != 0;
     return TCLIP_OK;
 }
 

@@ -58,6 +58,7 @@ _SIGNATURES = {
     "tclip_debug_set_probe_chunks": (ctypes.c_int, [ctypes.c_int32]),
     "tclip_debug_set_rowset_min_rows": (ctypes.c_int, [ctypes.c_int32]),
     "tclip_debug_set_mm_split": (ctypes.c_int, [ctypes.c_int32]),
+    "tclip_debug_set_split_keep_placement": (ctypes.c_int, [ctypes.c_int32]),
     "tclip_debug_set_fixed_k_kernels": (ctypes.c_int, [ctypes.c_int32]),
     "tclip_debug_set_kmeans_tile": (ctypes.c_int, [ctypes.c_int32]),
     "tclip_profile_last_kernels": (ctypes.c_int, [ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_double),
