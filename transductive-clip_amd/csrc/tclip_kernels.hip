@@ -1035,7 +1035,7 @@ __global__ __launch_bounds__(64 * W, (E > 16 ? TCLIP_MM_WAVES_LARGE : TCLIP_MM_W
                                        // phase C (RowY::fetch_all).  Round 4 kept 16 registers of y across the dense passes: the compiler
                                        // spilled them and re-read a pair at a time inside phase C, each re-read followed by a wait for
                                        // everything in flight.  Same-box A/B (profiles/r05_ab_phase_c.txt): K = 1000 -1.1 %, few-shot
-                                       // K = 1000 -1.2 %, K = 397 hard -0.9 % per engine call, bit-identical; VGPR spills 59 -> 22
+                                       // K = 1000 -1.2 %, K = 397 hard -0.9 % per engine call, bit-identical; VGPR spills 59 -> 23
 #endif
 #ifndef TCLIP_SPLIT_WAVES_SMALL
 #define TCLIP_SPLIT_WAVES_SMALL 4  // wavefronts per SIMD requested for up to 8 registers per lane
