@@ -17,7 +17,11 @@ feature table resident in HBM (indices drawn beforehand, identically on every ra
 reference's sampler), one engine call for the rank's batches, the accuracy tail (device prototypes,
 host assignment), and for N>1 the single RCCL all_gather of the per-task accuracies onto rank 0.
 
-Extra objects on the JSON line:
+stdout carries ONE compact JSON line (the contract's fields, `roofline`, `cpu_baseline`, one figure per secondary
+workload; a few kB - round 5's 20 kB line was more than the driver's reader takes); the full record described below
+goes to gpurun_out/bench_full.json and to stderr (`full_record` on the line names the file).
+
+Objects of the full record (the line carries their essential fields):
   roofline     the dominant kernels - k_mm_live (first outer iteration) and k_mm_split (the later ones), the MM loop of
                the live rows (`per_kernel`: each of the two alone) - timed live with HIP events around each of their launches on the streams they run on
                (independent batches use a few internal streams, so launches overlap: `achieved` divides by the time
@@ -32,8 +36,7 @@ Extra objects on the JSON line:
   secondary    the other BASELINE.json configs on one GPU, a few steps each, every one with its own roofline and an
                extrapolated cpu_baseline: `k100` = configs[1] (K=100), `k397_hard` = configs[2] (Hard EM-Dirichlet at
                K=397 plus SOFT_KMEANS on the same tasks), `fs_k1000` = configs[4] (visual embeddings -> probability
-               front-end -> 4-shot few-shot EM-Dirichlet at K=1000).  `secondary.value` etc. repeat `k100` at the top
-               level of the object (round-2 readers).
+               front-end -> 4-shot few-shot EM-Dirichlet at K=1000).
   cpu_baseline the torch-eager CPU restatement of the reference loop (oracle/ref_torch.py, kind "port") on this host:
                K=1000 is ~6 minutes per task on 8 cores, so, as SURVEY.md 8d prescribes, MM iterations of the first and
                of a later outer iteration plus one M/E-step are timed on a 2-task batch and extrapolated over the MM
@@ -63,8 +66,9 @@ N_QUERY = 75
 ITERS = 20
 ITER_MM = 1000
 HEADLINE = dict(name="k1000", K=1000, tasks_per_batch=125, batches_per_gpu=10, rows_per_class=50,
-                text="EM-Dirichlet zero-shot, K=1000 (imagenet-sized), 75-query, 1250 tasks per GPU as 10 batches of 125, "
-                     "iter=20, iter_mm=1000 (BASELINE.json configs[3]: 10 000 tasks on 8 GPUs = this per GPU)")
+                # the driver's record keeps the first 120 characters of this string: the schedule comes first
+                text="EM-Dirichlet zero-shot K=1000, 75-query, iter=20 x iter_mm=1000, fp32, 1250 tasks/GPU as 10 batches of 125 "
+                     "(BASELINE.json configs[3], imagenet-sized: 10 000 tasks on 8 GPUs = this per GPU)")
 SECONDARY = dict(name="k100", K=100, tasks_per_batch=100, batches_per_gpu=10, rows_per_class=40,
                  text="EM-Dirichlet zero-shot, K=100 (caltech101-sized), 75-query, 1000 tasks per GPU as 10 batches of 100, "
                       "iter=20, iter_mm=1000 (BASELINE.json configs[1])")
@@ -178,6 +182,9 @@ def cpu_baseline(w, mm_schedule, budget_s=300, iters_total=ITERS):
     spread = (max(values) - min(values)) / mean if len(values) > 1 else None
     return {"value": mean, "unit": "tasks/s", "cores": info["threads"], "kind": "port",
             "samples": values, "rel_spread": spread, **host,
+            "sample_short": f"{n_tasks}-task batch of the same K={K} workload, {len(values)} runs of 2 outer iterations x {ran} MM iterations, per-iteration "
+                            f"times extrapolated over the recorded schedule ({mm_schedule[0]} + {int(sum(mm_schedule[1:]))} MM iterations, SURVEY.md 8d); "
+                            f"{info['threads']} threads, torch {info['torch']} CPU eager",
             "sample": f"{n_tasks}-task batch of the same K={K}, 75-query workload, {len(values)} runs of 2 outer iterations with {ran} MM iterations each, "
                       f"extrapolated over the recorded schedule ({mm_schedule[0]} + {int(sum(mm_schedule[1:]))} MM iterations in "
                       f"{len(mm_schedule)} outer iterations, SURVEY.md 8d): " + " | ".join(f"run {i + 1}: {t}" for i, t in enumerate(texts)) +
@@ -212,6 +219,104 @@ def load_pmc():
             return json.load(f)
     except Exception:
         return None
+
+
+LINE_BUDGET = 6000          # bytes: the driver keeps a bounded tail of stdout; round 5's 20 kB line came back unparsed
+
+
+def _round(o, digits=6):
+    """floats to `digits` significant digits, recursively (the line is a record, not a checkpoint)"""
+    if isinstance(o, float):
+        return float(f"{o:.{digits}g}") if o == o and abs(o) != float("inf") else None
+    if isinstance(o, dict):
+        return {k: _round(v, digits) for k, v in o.items()}
+    if isinstance(o, (list, tuple)):
+        return [_round(v, digits) for v in o]
+    return o
+
+
+def _rle(seq):
+    """[501, 1000, 1000, ...] -> "501,1000x19" (the MM schedule of a batch)"""
+    out, i = [], 0
+    while i < len(seq):
+        j = i
+        while j < len(seq) and seq[j] == seq[i]:
+            j += 1
+        out.append(f"{seq[i]}x{j - i}" if j - i > 1 else f"{seq[i]}")
+        i = j
+    return ",".join(out)
+
+
+def _short_roofline(r):
+    keep = ("bound", "kernel", "achieved", "peak", "unit", "frac", "traffic", "traffic_algorithmic_bytes_per_launch",
+            "traffic_over_algorithmic", "avg_launch_ms", "launches_per_step", "kernel_busy_ms_per_step",
+            "element_updates_per_launch", "algorithmic_bytes_per_launch", "flop_eq_per_element_update", "measured_clock_ghz",
+            "frac_at_measured_clock", "pmc_stale")
+    out = {k: r[k] for k in keep if k in r}
+    if "per_kernel" in r:
+        out["per_kernel"] = {n: {k: v[k] for k in ("frac", "avg_launch_ms", "launches_per_step")} for n, v in r["per_kernel"].items()}
+    if "hbm" in r:
+        out["hbm"] = {k: r["hbm"][k] for k in ("achieved", "peak", "unit", "frac")}
+    src = r.get("traffic_source")
+    if src:
+        out["pmc"] = {k: src.get(k) for k in ("file", "lane_instr_per_update", "valu_busy_frac", "scratch_bytes_per_lane")}
+    return out
+
+
+def _short_cpu(c):
+    out = {k: c[k] for k in ("value", "unit", "cores", "kind", "samples", "rel_spread", "cpu_model", "cpus_usable", "loadavg_1min",
+                             "extrapolated") if k in c}
+    out["sample"] = c.get("sample_short") or c.get("sample", "")[:300]
+    return out
+
+
+def short_line(full, record_path):
+    """The ONE stdout line: the contract's fields, `roofline` and `cpu_baseline` in full meaning but without the
+    derivations' intermediate figures, one figure per secondary workload.  Everything else is in the full record
+    (`record_path`, also printed on stderr)."""
+    line = {k: v for k, v in full.items() if k not in ("roofline", "cpu_baseline", "secondary", "config")}
+    cfg = dict(full["config"])
+    if isinstance(cfg.get("mm_iters_batch0"), list):
+        cfg["mm_iters_batch0"] = _rle(cfg["mm_iters_batch0"])
+    line["config"] = cfg
+    line["roofline"] = _short_roofline(full["roofline"])
+    if "cpu_baseline" in full:
+        line["cpu_baseline"] = _short_cpu(full["cpu_baseline"])
+    if "secondary" in full:
+        sec = {}
+        for name, o in full["secondary"].items():
+            if not (isinstance(o, dict) and "roofline" in o):   # records up to round 5 repeated k100's fields beside the three objects
+                continue
+            sec[name] = {"value": o["value"], "unit": o["unit"], "ms_per_step": o["ms_per_step"],
+                         "roofline_frac": o["roofline"]["frac"]}
+            if o.get("cpu_baseline"):
+                sec[name]["cpu_baseline"] = o["cpu_baseline"].get("value")
+            if "soft_kmeans" in o:
+                sec[name]["soft_kmeans"] = o["soft_kmeans"]["value"]
+        line["secondary"] = sec
+    line["full_record"] = record_path
+    line = _round(line)
+    text = json.dumps(line, separators=(",", ":"))
+    if len(text) > LINE_BUDGET:                          # never again a line the driver cannot take: shed the optional parts
+        for k in ("secondary", "rank_devices", "rank_step_ms"):
+            line.pop(k, None)
+        line["roofline"].pop("per_kernel", None)
+        text = json.dumps(line, separators=(",", ":"))
+    return text
+
+
+def write_record(full):
+    """Full record: gpurun_out/bench_full.json (merged back by gpurun; the committed copies live under profiles/) and stderr."""
+    rel = os.path.join("gpurun_out", "bench_full.json")
+    try:
+        os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
+        with open(os.path.join(ROOT, rel), "w") as f:
+            json.dump(full, f)
+            f.write("\n")
+    except OSError:
+        rel = "stderr"
+    print("bench full record: " + json.dumps(full), file=sys.stderr, flush=True)
+    return rel
 
 
 def roofline_of(prof, steps, K, pmc_key):
@@ -514,12 +619,12 @@ def main():
 
     if world == 1 and not args.no_secondary and args.workload == "k1000":
         sec = {name: fn() for name, fn in runners.items()}
-        line["secondary"] = dict(sec["k100"], **sec)
+        line["secondary"] = sec
 
     if rank == 0:
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(head, mm_iters[0].tolist(), budget_s=120)
-        print(json.dumps(line), flush=True)
+        print(short_line(line, write_record(line)), flush=True)
     if dist_on:
         dist.barrier()
         dist.destroy_process_group()

@@ -213,3 +213,32 @@ def test_source_digest_ignores_comments_not_code(tmp_path, monkeypatch):
     monkeypatch.setattr(bench._capi, "source_digest", lambda: "0" * 40)
     stale = bench.roofline_of((10.0, 10.0, 4, 10 ** 9), 1, 1000, "k1000")
     assert stale["traffic"] is None and "measured_clock_ghz" not in stale and stale["pmc_stale"]["file"] == pmc["k1000"]["file"]
+
+
+def test_bench_stdout_line_stays_small():
+    """The driver reads bench.py's ONE stdout line through a bounded buffer: round 5's 20 kB line (three secondary workloads
+    with their derivations) came back as `parsed: null`.  The line is now a digest of the full record (which goes to
+    gpurun_out/bench_full.json and stderr): every field the contract names, roofline with traffic and the per-launch figures,
+    cpu_baseline with both samples - in a few kB whatever the secondaries carry."""
+    import json
+    import sys
+    sys.path.insert(0, ROOT)
+    import bench
+    full = json.load(open(os.path.join(ROOT, "profiles", "r05_bench.json")))          # a complete record of the old format
+    text = bench.short_line(full, "gpurun_out/bench_full.json")
+    assert len(text) < 4096 and "\n" not in text
+    d = json.loads(text)
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline",
+              "dtype", "data", "config", "roofline", "cpu_baseline"):
+        assert k in d, k
+    assert len(d["config"]["workload"]) > 20 and "model" not in d["config"]
+    for k in ("bound", "achieved", "peak", "unit", "frac", "traffic", "avg_launch_ms"):
+        assert k in d["roofline"], k
+    assert abs(d["roofline"]["frac"] - d["roofline"]["achieved"] / d["roofline"]["peak"]) < 1e-5
+    for k in ("value", "unit", "cores", "kind", "sample"):
+        assert k in d["cpu_baseline"], k
+    assert set(d["secondary"]) >= {"k100", "k397_hard", "fs_k1000"} and d["config"]["mm_iters_batch0"] == "501,1000x19"
+    # a record that would still be too long sheds its optional parts instead of growing the line
+    full["config"]["path"] = "x" * 8000
+    assert "secondary" not in json.loads(bench.short_line(full, "f"))
+    assert bench._rle([201, 251, 51, 51, 51]) == "201,251,51x3"
