@@ -224,7 +224,7 @@ def load_pmc():
 LINE_BUDGET = 6000          # bytes: the driver keeps a bounded tail of stdout; round 5's 20 kB line came back unparsed
 
 
-def _round(o, digits=6):
+def _round(o, digits=8):
     """floats to `digits` significant digits, recursively (the line is a record, not a checkpoint)"""
     if isinstance(o, float):
         return float(f"{o:.{digits}g}") if o == o and abs(o) != float("inf") else None

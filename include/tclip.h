@@ -28,14 +28,17 @@ extern "C" {
 /* 2: tclip_alpha_tim_run, tclip_laplacian_shot_run, tclip_match_clusters_host_strided, tclip_debug_set_mm_split added
  * 3: tclip_em_dirichlet_run_tasks (tclip_task_source) added
  * 4: tclip_check_task_indices, tclip_profile_last_split_sorts, tclip_debug_set_split_keep_placement added
+ * 5: TCLIP_ERR_INDEX: tclip_check_task_indices reports an out-of-range VALUE with its own code (bad arguments stay TCLIP_ERR_ARG);
+ *    tclip_debug_set_dead_head added
  * (every entry point of an earlier version keeps its signature) */
-#define TCLIP_ABI_VERSION 4
+#define TCLIP_ABI_VERSION 5
 
 enum {
     TCLIP_OK = 0,
     TCLIP_ERR_ARG = 1,        /* bad argument (null pointer, non-positive size, K out of range) */
     TCLIP_ERR_WORKSPACE = 2,  /* workspace too small or misaligned */
-    TCLIP_ERR_HIP = 3         /* a HIP call failed; text in tclip_last_error() */
+    TCLIP_ERR_HIP = 3,        /* a HIP call failed; text in tclip_last_error() */
+    TCLIP_ERR_INDEX = 4       /* tclip_check_task_indices: a value of an index tensor lies outside its table (torch: IndexError) */
 };
 
 /* One call = n_batches independent reference batches of tasks_per_batch tasks each.  Tasks of
@@ -103,8 +106,9 @@ int tclip_em_dirichlet_run_tasks(const tclip_problem* p, const tclip_task_source
  * `all_features_query[indices, :]` (src/eval_zero_shot.py:160-163, src/eval_few_shot.py:233-241) does by raising IndexError:
  *   idx  device [n_idx]  i64, every value must lie in [0, n_rows)         (NULL with n_idx == 0: nothing to check)
  *   cols device [n_cols] i32, every value must lie in [0, n_class)        (NULL with n_cols == 0)
- * One pass over each on `stream`, then the call WAITS for the stream and returns TCLIP_ERR_ARG (text in tclip_last_error)
- * when a value is out of range, TCLIP_OK otherwise.  Negligible next to the loop it protects (a few microseconds per
+ * One pass over each on `stream`, then the call WAITS for the stream (hipStreamSynchronize: a host sync per call) and returns
+ * TCLIP_ERR_INDEX (text in tclip_last_error) when a value is out of range - negative values included: they are rejected, not
+ * wrapped as torch wraps them -, TCLIP_ERR_ARG for a null pointer / negative count, TCLIP_OK otherwise.  Negligible next to the loop it protects (a few microseconds per
  * million indices); keeps one int32 of device memory per calling thread. */
 int tclip_check_task_indices(const int64_t* idx, int64_t n_idx, int64_t n_rows, const int32_t* cols, int64_t n_cols,
                              int32_t n_class, void* stream);
@@ -300,6 +304,13 @@ int tclip_debug_set_split_keep_placement(int32_t on);
  * For tests: 0 disables the probe (every dead row iterates its whole schedule once), negative
  * restores the default.  Process-wide; results do not depend on it. */
 int tclip_debug_set_probe_chunks(int32_t chunks);
+
+/* Rows that have just died run only their first `iterations` MM iterations (default 16) before an early probe looks for
+ * the limit cycle from there on (a second snapshot 32 iterations later finds rows that were still approaching their cycle);
+ * rows it cannot finish take the path above from the start.  For tests: 0 disables the early probe (the path above for
+ * every dead row), negative restores the default, more than 18 is refused (TCLIP_ERR_ARG).  Also off while
+ * tclip_debug_set_probe_chunks(0) is in force.  Process-wide; results do not depend on it. */
+int tclip_debug_set_dead_head(int32_t iterations);
 
 /* Rows of up to 256 elements are spread over 16 lanes in the MM kernels (4 rows per wavefront), longer ones
  * over 32.  For tests: 0 forces the 32-lane layout for every row length, negative restores the default rule.

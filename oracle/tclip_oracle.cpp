@@ -439,3 +439,36 @@ extern "C" double tclip_oracle_min_stop_margin(int reset) {
     if (reset) g_min_stop_margin = 1e300;
     return m;
 }
+
+// Third design-study hook (scripts/dead_row_cycles.py): the trajectory of ONE dead row (y = -10 everywhere, em_dirichlet.py:222-223)
+// started at `row`: mu = first iteration whose state is met again later (length of the transient), period = length of the
+// limit cycle of the fp32 map; -1 / -1 when no state repeats within max_iter iterations.
+extern "C" void tclip_oracle_dead_row_cycle(const float* row, int K, int max_iter, int32_t* mu, int32_t* period) {
+    std::vector<float> cur(row, row + K), next(K), y(K, -10.0f);
+    std::vector<uint64_t> seen;
+    std::vector<std::vector<float>> states;
+    *mu = -1;
+    *period = -1;
+    for (int l = 0; l <= max_iter; l++) {
+        const uint64_t h = row_hash(cur.data(), K);
+        for (int j = (int)seen.size() - 1; j >= 0; j--)
+            if (seen[j] == h && memcmp(states[j].data(), cur.data(), sizeof(float) * K) == 0) {
+                *mu = j;
+                *period = l - j;
+                return;
+            }
+        seen.push_back(h);
+        states.push_back(cur);
+        mm_step_row(cur.data(), y.data(), next.data(), K);
+        cur.swap(next);
+    }
+}
+// ... and the state after `iters` iterations of that trajectory (out: K floats), for a look at what the cycle's states consist of
+extern "C" void tclip_oracle_dead_row_state(const float* row, int K, int iters, float* out) {
+    std::vector<float> cur(row, row + K), next(K), y(K, -10.0f);
+    for (int l = 0; l < iters; l++) {
+        mm_step_row(cur.data(), y.data(), next.data(), K);
+        cur.swap(next);
+    }
+    memcpy(out, cur.data(), sizeof(float) * K);
+}

@@ -26,7 +26,7 @@ def test_library_exports_every_declared_symbol():
     for n in names:
         assert hasattr(lib, n), f"{n} declared in include/tclip.h but not exported"
     assert set(_capi.EXPORTS) == set(names)
-    assert lib.tclip_abi_version() == 4
+    assert lib.tclip_abi_version() == 5
 
 
 def test_workspace_size_and_argument_checks():

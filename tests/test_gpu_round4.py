@@ -361,6 +361,14 @@ def test_table_fed_entry_equals_materialised_tensors(K, N, B, shots, perm, hard)
             engine.run_em_dirichlet_tasks(tq, q_dev, ts, s_idx, y_s, bad_c, **kw)
     with pytest.raises(IndexError):
         engine.gather_rows(tq, torch.tensor([0, tab_q.shape[0]], device=DEV))
+    # (round 6) only an out-of-range VALUE is an IndexError (TCLIP_ERR_INDEX = 4); a bad argument to the check itself stays what
+    # it is for every other entry point: TCLIP_ERR_ARG = 1
+    from tclip_amd import _capi
+    st = torch.cuda.current_stream().cuda_stream
+    assert _capi.lib().tclip_check_task_indices(bad.data_ptr(), bad.numel(), tab_q.shape[0], None, 0, 1, st) == 4
+    assert _capi.lib().tclip_check_task_indices(q_dev.data_ptr(), q_dev.numel(), tab_q.shape[0], None, 0, 1, st) == 0
+    assert _capi.lib().tclip_check_task_indices(None, 5, tab_q.shape[0], None, 0, 1, st) == 1
+    assert _capi.lib().tclip_check_task_indices(q_dev.data_ptr(), -1, tab_q.shape[0], None, 0, 1, st) == 1
 
 
 # ---------------------------------------------------------------------------------------------------------------------

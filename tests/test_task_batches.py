@@ -222,6 +222,9 @@ def _worker_eight(rank, world, port, out):
     # two nodes of four GPUs each: device indices 0..3 repeat across the nodes and must be accepted (until round 5 the check
     # compared bare indices over the whole world and refused every correct multi-node job)
     assert sharding.check_one_device_per_rank(rank % 4, node_key=1000 + rank // 4) == [r % 4 for r in range(world)]
+    # a launcher that hands every rank ONE GPU through HIP_VISIBLE_DEVICES: every rank sees index 0, on eight different devices
+    # (told apart by uuid / PCI address: `device_key` stands in for it here)
+    assert sharding.check_one_device_per_rank(0, device_key=7000 + rank) == [0] * world
     try:
         sharding.check_one_device_per_rank(rank % 2, node_key=1000 + rank // 4)      # ... but not two ranks of ONE node on a device
         shared_refused = False
@@ -250,6 +253,17 @@ def test_eight_ranks_gather_configs3_records_gloo(tmp_path):
     secs = r["secs"]
     skew = (max(secs) - min(secs)) / max(secs)
     assert len(secs) == 8 and 0 < skew < 0.01
+
+
+def test_node_key_comes_from_the_launcher():
+    """the node of a rank: the launcher's GROUP_RANK, else RANK // LOCAL_WORLD_SIZE, else (only then) a host-name hash - nodes or
+    containers that share a host name are still told apart under torch.distributed.run"""
+    assert sharding._node_key({"GROUP_RANK": "3", "RANK": "25", "LOCAL_WORLD_SIZE": "8"}) == 3.0
+    assert sharding._node_key({"RANK": "25", "LOCAL_WORLD_SIZE": "8"}) == 3.0
+    assert sharding._node_key({"RANK": "7", "LOCAL_WORLD_SIZE": "8"}) == 0.0
+    h = sharding._node_key({})
+    assert h == sharding._node_key({"RANK": "5"}) and h > 2 ** 20 and float(int(h)) == h       # host-name hash, exact in float64
+    assert sharding._device_key(3) == 3.0                                   # no GPU in this process: the index itself
 
 
 def test_host_thread_cap_respects_local_world_size(monkeypatch):

@@ -799,6 +799,94 @@ __global__ __launch_bounds__(256, (E > 16 ? TCLIP_MM_WAVES_LARGE : TCLIP_MM_WAVE
     }
 }
 
+// Early limit-cycle probe (round 6) for rows that have JUST died: k_mm_live<.., true> has run only the first `a.l0`
+// iterations (TCLIP_DEAD_HEAD, not the whole first chunk) and left b_{l0} in `beta_dead`.
+// Measured on the reference's trajectories (scripts/dead_row_cycles.py, CPU oracle, the alpha rows of a task after its first
+// outer iteration): a dead row is ON its cycle after 8..15 iterations at K = 100 (median 10; periods 1, 2, 4) and after
+// 8..28 at K = 1000 (median 11, 99 % within 16; periods 20 (75 %), 5, 4, 8) - so the 51 iterations of chunk 0 that
+// k_mm_probe waits for are mostly spent going round the cycle.  Here the probe starts at iteration l0, measures the pair
+// (||b'-b||^2, ||b||^2) of EVERY iteration it executes (cyc[j]: iteration l0 + j) and compares the state with a snapshot:
+// b_{l0} itself for the first 32 iterations, the state after them from then on (a snapshot taken before the row reached its
+// cycle is never met again, a later one is; the first version renewed it after 4, 8, 16 and 32 iterations and met the
+// 20-iteration cycles of K = 1000 only through the last one, after 52 iterations - a snapshot must stand for a whole period).
+// State s_{j+1} == snapshot s_js: the trajectory is periodic from iteration l0 + js on
+// with period p = j + 1 - js, and the pair of iteration l >= l0 + js is cyc[js + (l - l0 - js) mod p] - every checkpoint of
+// the row (l = 50, 100, ...; l0 + 32 <= 50 is checked on the host) is filled and the row is done, exactly as if it had run.
+// No cycle within kMaxCycle iterations, or a row whose cache is partly filled (a batch that stopped early): the row goes to
+// the list `next_rows`, which the host hands to the old path (k_mm_live<.., true> over the whole chunk from alpha, then
+// k_mm_probe) - nothing is assumed about such a row.
+#ifndef TCLIP_DEAD_HEAD
+#define TCLIP_DEAD_HEAD 16
+#endif
+template <int E, int G>
+__global__ __launch_bounds__(256, (E > 16 ? TCLIP_MM_WAVES_LARGE : TCLIP_MM_WAVES_SMALL)) void k_mm_probe_head(MMArgs a) {
+    __shared__ LogTabEntry tab[16];
+    __shared__ double cyc[256 / G][kMaxCycle][2];
+    __shared__ float lg_queue[4][64 * E];
+    load_log_table(tab);
+    float* queue = lg_queue[threadIdx.x >> 6];
+    const int lane = threadIdx.x & (G - 1);
+    const int group = threadIdx.x / G;
+    const int groups_per_block = blockDim.x / G;
+    const int n = *a.n_rows;
+    const int K = a.K;
+    for (int i = blockIdx.x * groups_per_block + group; i < n; i += gridDim.x * groups_per_block) {
+        const int row = a.rows[i];
+        if (a.stop[row / a.rows_per_batch]) continue;
+        if (a.cache_len[row] != 0) {                                // partly cached: the old path continues it where it stands
+            if (lane == 0) a.next_rows[atomicAdd(a.next_count, 1)] = row;
+            continue;
+        }
+        float* ref = a.beta_dead + (size_t)row * K;                // b_{l0}; overwritten by the later snapshots
+        float beta[E];
+        RowY<E, G> yv;
+        yv.load(nullptr, lane, K);
+#pragma unroll
+        for (int e = 0; e < E; e++) {
+            const int d = elem_of<E, G>(e, lane);
+            beta[e] = d < K ? ref[d] : 0.0f;
+        }
+        int period = 0, js = 0;
+        for (int j = 0; j < kMaxCycle && period == 0; j++) {
+            double pn = 0.0, pd = 0.0;
+            mm_iterate<E, G>(beta, yv, K, lane, tab, queue, true, pn, pd);
+            pn = group_sum_f64_g<G>(pn);
+            pd = group_sum_f64_g<G>(pd);
+            if (lane == 0) { cyc[group][j][0] = pn; cyc[group][j][1] = pd; }
+            bool same = true;
+#pragma unroll
+            for (int e = 0; e < E; e++) {
+                const int d = elem_of<E, G>(e, lane);
+                if (d < K) same = same && (beta[e] == ref[d]);
+            }
+            const unsigned long long bal = __ballot(same);
+            constexpr unsigned long long kAll = G == 64 ? ~0ull : (1ull << (G & 63)) - 1ull;
+            const unsigned long long mine = (bal >> ((threadIdx.x & 63) & ~(G - 1))) & kAll;      // this group's lanes
+            if (mine == kAll) {
+                period = j + 1 - js;
+            } else if (j + 1 == 32) {                                                              // a new snapshot: s_{j+1}
+                js = j + 1;
+#pragma unroll
+                for (int e = 0; e < E; e++) {
+                    const int d = elem_of<E, G>(e, lane);
+                    if (d < K) ref[d] = beta[e];
+                }
+            }
+        }
+        if (period && lane == 0) {
+            for (int m = 0; m < a.n_checks; m++) {
+                const int t = 50 * (m + 1) - a.l0;                  // cyc index of the checkpoint's iteration, were the window long enough
+                const int j = js + (t - js) % period;
+                double* c = a.cache + ((size_t)row * a.n_checks + m) * 2;
+                c[0] = cyc[group][j][0];
+                c[1] = cyc[group][j][1];
+            }
+            a.cache_len[row] = a.n_checks;
+        }
+        if (!period && lane == 0) a.next_rows[atomicAdd(a.next_count, 1)] = row;
+    }
+}
+
 // ------------------------------------------------------------------------------------------
 // Live rows: the same iteration, with the large-x lgamma queue shared by the whole BLOCK.
 // A wave of two rows queues only ~10-20 large arguments per iteration, so the per-wave dense pass
@@ -1455,14 +1543,8 @@ __global__ __launch_bounds__(64, (E > 16 ? TCLIP_MM_WAVES_LARGE : (E > 8 ? TCLIP
         for (int l = a.l0; l <= a.l1; l++)
             mm_iterate_wave_split<E, G, KC>(beta, yv, K, lane, active, tab, plane0, plane1, a.has_check && l == a.l1, num, den, pl,
                                             a.keep_placement != 0);
-        if (!active) continue;
-#pragma unroll
-        for (int e = 0; e < E; e++) {
-            const int d = elem_of<E, G>(e, lane);
-            if (d < K) a.alpha[(size_t)row * K + d] = beta[e];
-        }
-        if (a.work_counter && lane == 0)
-            atomicAdd(a.work_counter, (unsigned long long)K * (unsigned long long)(a.l1 - a.l0 + 1));
+        // per-wavefront instrumentation by lane 0 whether or not ITS lane group has a row (in the 16- and 32-lane layouts the
+        // wavefront iterates as long as any of its groups does: __any(active) above)
 #ifdef TCLIP_PHASE_CLOCK
         if ((threadIdx.x & 63) == 0)
             for (int i = 0; i < 8; i++) atomicAdd(&g_phase_clock[i], (unsigned long long)pl.clk[i]);
@@ -1471,6 +1553,14 @@ __global__ __launch_bounds__(64, (E > 16 ? TCLIP_MM_WAVES_LARGE : (E > 8 ? TCLIP
             atomicAdd(a.work_counter + 1, (unsigned long long)(a.l1 - a.l0 + 1));
             atomicAdd(a.work_counter + 2, (unsigned long long)pl.sorts);
         }
+        if (!active) continue;
+#pragma unroll
+        for (int e = 0; e < E; e++) {
+            const int d = elem_of<E, G>(e, lane);
+            if (d < K) a.alpha[(size_t)row * K + d] = beta[e];
+        }
+        if (a.work_counter && lane == 0)
+            atomicAdd(a.work_counter, (unsigned long long)K * (unsigned long long)(a.l1 - a.l0 + 1));
         if (a.has_check) {
             const double sn = group_sum_f64_g<G>(num), sd = group_sum_f64_g<G>(den);
             if (lane == 0) {
@@ -2718,6 +2808,7 @@ struct Profile {
 static thread_local bool g_last_mm_was_split = false;     // which kernel the last launch_mm(kMMSplit / kMMLive) started
 thread_local Profile g_prof;
 static int g_probe_chunks = TCLIP_PROBE_CHUNKS;     // tclip_debug_set_probe_chunks
+static int g_dead_head = TCLIP_DEAD_HEAD;           // tclip_debug_set_dead_head: iterations a fresh dead row runs before the early probe; 0 = no early probe
 static int g_rowset_min_rows = -1;                  // tclip_debug_set_rowset_min_rows; negative: the default rule
 static int g_mm_split = -1;                         // tclip_debug_set_mm_split: 0 never, 1 always, negative: from the second outer iteration on
 static int g_split_keep_placement = 1;              // tclip_debug_set_split_keep_placement: 0 = k_mm_split sorts its queues in every iteration
@@ -2734,7 +2825,7 @@ static hipEvent_t prof_event() {
 constexpr int kDecideSlices = 64;     // blocks per batch in the first stage of the stop test (large batches)
 struct Layout {
     size_t logz, y, alpha_old, beta_dead, sup, cnt, cs, live, rowc, logit0, cache, cache_len, rowpart, mm_rows,
-        mm_rows2, dead_counts, live_rows, counts, flags, stop, ratio, dpart, total;
+        mm_rows2, mm_rows3, dead_counts, live_rows, counts, flags, stop, ratio, dpart, total;
     int n_checks;
 };
 
@@ -2763,7 +2854,8 @@ static Layout make_layout(const tclip_problem& p) {
     L.rowpart = take(T * K * 16);
     L.mm_rows = take(T * K * 4);
     L.mm_rows2 = take(zs ? T * K * 4 : 0);
-    L.dead_counts = take(((size_t)n_chunks_of(p.iter_mm) + 2) * 4);
+    L.mm_rows3 = take(zs ? T * K * 4 : 0);                    // rows the early probe hands back to the old dead-row path
+    L.dead_counts = take(((size_t)n_chunks_of(p.iter_mm) + 3) * 4);    // [chunk] + one spare + [n_chunks + 2]: length of mm_rows3
     L.live_rows = take(T * K * 4);
     L.counts = take(256);
     L.flags = take(256);
@@ -2824,7 +2916,7 @@ static void dispatch_E(int K, Args... args) {
 #ifndef TCLIP_MM_LAUNCH_WAVES
 #define TCLIP_MM_LAUNCH_WAVES 4
 #endif
-enum MMKind { kMMLive = 0, kMMDead = 1, kMMProbe = 2, kMMSplit = 3 };
+enum MMKind { kMMLive = 0, kMMDead = 1, kMMProbe = 2, kMMSplit = 3, kMMProbeHead = 4 };
 template <int E, int G, int KC = 0>
 static void launch_mm_EG(int dead, int rows, hipStream_t st, const MMArgs& a) {
     constexpr int kWaves = TCLIP_MM_LAUNCH_WAVES, kRowsPerBlock = (64 / G) * kWaves;
@@ -2842,7 +2934,9 @@ static void launch_mm_EG(int dead, int rows, hipStream_t st, const MMArgs& a) {
         dead = kMMLive;
     }
     if (dead == kMMProbe) hipLaunchKernelGGL((k_mm_probe<E, G>), dim3(grid), dim3(256), 0, st, a);
-    else if (dead) hipLaunchKernelGGL((k_mm_live<E, kWaves, true, 1, G, KC>), dim3(grid), dim3(64 * kWaves), 0, st, a);
+    else if (dead == kMMProbeHead) {
+        if constexpr (KC == 0) hipLaunchKernelGGL((k_mm_probe_head<E, G>), dim3(grid), dim3(256), 0, st, a);      // (launch_mm: probes have no fixed-K build)
+    } else if (dead) hipLaunchKernelGGL((k_mm_live<E, kWaves, true, 1, G, KC>), dim3(grid), dim3(64 * kWaves), 0, st, a);
     else hipLaunchKernelGGL((k_mm_live<E, kWaves, false, 1, G, KC>), dim3(grid), dim3(64 * kWaves), 0, st, a);
 }
 template <int G>
@@ -2898,7 +2992,7 @@ static bool mm_has_split(int K) {
 static int g_fixed_k_kernels = TCLIP_FIXED_K_DEFAULT;
 static void launch_mm(int dead, int K, int rows, hipStream_t st, const MMArgs& a) {
     const bool wide = g_rowset_min_rows == 0;              // test hook: the 32-lane layout for every row length
-    if (!wide && g_fixed_k_kernels && dead != kMMProbe) {
+    if (!wide && g_fixed_k_kernels && dead != kMMProbe && dead != kMMProbeHead) {
 #if TCLIP_G64_MIN_K > 0 && TCLIP_G64_MIN_K <= 1000
         if (K == 1000) return launch_mm_EG<16, 64, 1000>(dead, rows, st, a);
 #endif
@@ -3235,6 +3329,7 @@ static int enqueue_batches(const tclip_problem& p, const RowSrc& q_src, const Ro
     int32_t* mm_rows = (int32_t*)(ws + L.mm_rows);
     int32_t* dead_list[2] = {mm_rows, zs ? (int32_t*)(ws + L.mm_rows2) : mm_rows};   // chunk c sweeps dead_list[c & 1]
     int32_t* dead_counts = (int32_t*)(ws + L.dead_counts);                        // [chunk] length of that list
+    int32_t* head_back = zs ? (int32_t*)(ws + L.mm_rows3) : nullptr;              // rows the early probe could not finish
     int32_t* live_rows = (int32_t*)(ws + L.live_rows);
     int32_t* counts = (int32_t*)(ws + L.counts);
     int32_t* flags = (int32_t*)(ws + L.flags);          // [0]: some log z is not finite
@@ -3284,7 +3379,7 @@ static int enqueue_batches(const tclip_problem& p, const RowSrc& q_src, const Ro
                            cs, live, v, cache_len);
         launch_mstats(st, (const float*)u, (const float*)logz, (const float*)cs, (const uint8_t*)live, (const float*)sup, (const float*)cnt, T, Q, K, y, 0);
         TCLIP_HIP(hipMemsetAsync(counts, 0, 256, st));
-        TCLIP_HIP(hipMemsetAsync(dead_counts, 0, ((size_t)n_chunks + 2) * 4, st));
+        TCLIP_HIP(hipMemsetAsync(dead_counts, 0, ((size_t)n_chunks + 3) * 4, st));
         TCLIP_HIP(hipMemsetAsync(stop, 0, (size_t)B * 4, st));
         hipLaunchKernelGGL(k_build_rows, dim3((TK + 255) / 256), dim3(256), 0, st, (const uint8_t*)live,
                            (const int32_t*)cache_len, TK, n_checks, dead_list[0], live_rows, dead_counts, counts + 1);
@@ -3317,6 +3412,16 @@ static int enqueue_batches(const tclip_problem& p, const RowSrc& q_src, const Ro
             if (split_runs != g_last_mm_was_split) return fail(TCLIP_ERR_ARG, "internal: mm_has_split disagrees with launch_mm");
             if (zs && a.has_check) {          // dead rows only matter through their stop-test terms
                 a.rows = dead_list[c & 1]; a.n_rows = dead_counts + c; a.work_counter = nullptr;
+                if (c == 0 && g_dead_head > 0 && g_probe_chunks > 0) {
+                    // rows that have just died: TCLIP_DEAD_HEAD iterations, then the early probe (k_mm_probe_head), which finishes
+                    // every row it finds on its cycle; what is left over takes the path below from the start
+                    MMArgs h = a;
+                    h.l0 = 0; h.l1 = g_dead_head - 1; h.has_check = 0; h.next_rows = nullptr; h.next_count = nullptr;
+                    launch_mm(kMMDead, K, TK, st, h);
+                    h.l0 = g_dead_head; h.next_rows = head_back; h.next_count = dead_counts + n_chunks + 2;
+                    launch_mm(kMMProbeHead, K, TK, st, h);
+                    a.rows = head_back; a.n_rows = dead_counts + n_chunks + 2;
+                }
                 // the probe needs the row to be ON its cycle already; rows that were still approaching
                 // it after chunk 0 get a few more chances before they are left to iterate every chunk
                 const bool more = c + 1 < a.n_checks, probe = c < g_probe_chunks && more;
@@ -3967,6 +4072,12 @@ int tclip_debug_set_split_keep_placement(int32_t on) {
     return TCLIP_OK;
 }
 
+int tclip_debug_set_dead_head(int32_t iterations) {
+    // the early probe needs its last snapshot (32 iterations in) to lie at or before the first checkpoint (iteration 50)
+    if (iterations > 18) return fail(TCLIP_ERR_ARG, "tclip_debug_set_dead_head: at most 18 iterations");
+    g_dead_head = iterations < 0 ? TCLIP_DEAD_HEAD : iterations;
+    return TCLIP_OK;
+}
 int tclip_debug_set_probe_chunks(int32_t chunks) {
     g_probe_chunks = chunks < 0 ? TCLIP_PROBE_CHUNKS : chunks;
     return TCLIP_OK;
@@ -4128,8 +4239,8 @@ int tclip_check_task_indices(const int64_t* idx, int64_t n_idx, int64_t n_rows, 
     int32_t h = 0;
     TCLIP_HIP(hipMemcpyAsync(&h, flag, sizeof h, hipMemcpyDeviceToHost, st));
     TCLIP_HIP(hipStreamSynchronize(st));
-    if (h & 1) return fail(TCLIP_ERR_ARG, "index out of range for the feature table");
-    if (h & 2) return fail(TCLIP_ERR_ARG, "column index out of range");
+    if (h & 1) return fail(TCLIP_ERR_INDEX, "index out of range for the feature table");
+    if (h & 2) return fail(TCLIP_ERR_INDEX, "column index out of range");
     return TCLIP_OK;
 }
 

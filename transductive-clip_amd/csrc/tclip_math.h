@@ -467,7 +467,7 @@ TCLIP_HD float lgamma_sleef_ge23(float a) {
 // v lies within ~2^-43 (relative) of the midpoint of two floats - `sure` says it is 2^-40 or more away (the hi word of
 // the shift product is a rounding of the same kind and has its own window); callers send the rest through
 // lgamma_sleef_ge23.  oracle/mathcheck.cpp compares the two forms on EVERY float of [2.3, 2^41]
-// (tests/test_math_host.py; scripts/check_lgamma_ge23.py for the complete sweep) and k_selftest on the device.
+// (tests/test_math_host.py runs the complete sweep, stride 1) and k_selftest on the device.
 constexpr int kGe23WindowLog2 = 13;        // |position - midpoint| <= 2^13 of the 2^29 sub-float positions is "unsure" (3e-5 of the
                                            // arguments); the largest distance at which the two forms differ anywhere in the domain is 956
 TCLIP_HD bool f64_rounds_surely_to_f32(double v, int window_log2) {

@@ -56,6 +56,7 @@ _SIGNATURES = {
     "tclip_selftest_primitives": (ctypes.c_int, [ctypes.POINTER(ctypes.c_uint64)]),
     "tclip_profile_enable": (ctypes.c_int, [ctypes.c_int]),
     "tclip_debug_set_probe_chunks": (ctypes.c_int, [ctypes.c_int32]),
+    "tclip_debug_set_dead_head": (ctypes.c_int, [ctypes.c_int32]),
     "tclip_debug_set_rowset_min_rows": (ctypes.c_int, [ctypes.c_int32]),
     "tclip_debug_set_mm_split": (ctypes.c_int, [ctypes.c_int32]),
     "tclip_debug_set_split_keep_placement": (ctypes.c_int, [ctypes.c_int32]),
@@ -93,7 +94,7 @@ def lib():
         for name, (res, args) in _SIGNATURES.items():
             fn = getattr(l, name)
             fn.restype, fn.argtypes = res, args
-        if l.tclip_abi_version() != 4:
+        if l.tclip_abi_version() != 5:
             raise RuntimeError("libtclip.so ABI version mismatch")
         _lib = l
     return _lib

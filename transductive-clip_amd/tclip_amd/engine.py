@@ -94,19 +94,23 @@ def run_em_dirichlet(x_q, x_s=None, y_s=None, *, n_batches=1, iters, iter_mm=100
 
 
 def _check_on_device(idx, n_rows, cols, n_class, name):
-    """tclip_check_task_indices on device-resident tensors: IndexError where torch's own `table[idx]` would raise one"""
+    """tclip_check_task_indices on device-resident tensors: IndexError where torch's own `table[idx]` would raise one
+    (TCLIP_ERR_INDEX only; a bad argument is a RuntimeError like every other failed call).  Negative values are rejected,
+    not wrapped as torch wraps them - on the host path (`_index_tensor`) too.  The call waits for the stream: one host
+    synchronisation per checked tensor."""
     with torch.cuda.device(idx.device if idx is not None else cols.device):
         rc = _capi.lib().tclip_check_task_indices(_ptr(idx) if idx is not None else None, idx.numel() if idx is not None else 0, max(1, int(n_rows)),
                                                   _ptr(cols) if cols is not None else None, cols.numel() if cols is not None else 0, int(n_class), _stream())
-    if rc == 1:                             # TCLIP_ERR_ARG
+    if rc == 4:                             # TCLIP_ERR_INDEX
         raise IndexError(f"{name}: {_capi.lib().tclip_last_error().decode()}")
     _capi.check(rc, "tclip_check_task_indices")
 
 
 def _index_tensor(idx, n_rows, dev, name):
     """int64 (T,R) index tensor on the device, every value checked against the table's row count as torch's own
-    `table[idx]` checks it (IndexError): on the host when that is where the tensor is (the samplers produce CPU tensors),
-    by one pass on the device otherwise (tclip_check_task_indices)"""
+    `table[idx]` checks it (IndexError; negative values are rejected, not wrapped): on the host when that is where the tensor
+    is (the samplers produce CPU tensors), by one pass on the device otherwise (tclip_check_task_indices, which synchronises
+    the stream: a caller that keeps its index tensors on the device pays one host sync per call)"""
     idx = idx.long()
     if not idx.is_cuda:
         if idx.numel() and (int(idx.min()) < 0 or int(idx.max()) >= n_rows):
@@ -353,6 +357,12 @@ def debug_set_probe_chunks(chunks=-1):
     """Test hook: run the dead rows' limit-cycle probe after the first `chunks` chunks (0 = never,
     negative = default).  Results do not depend on it."""
     _capi.check(_capi.lib().tclip_debug_set_probe_chunks(int(chunks)), "tclip_debug_set_probe_chunks")
+
+
+def debug_set_dead_head(iterations=-1):
+    """Test hook: MM iterations a freshly dead row runs before the early limit-cycle probe (0 = no early probe: the whole first
+    chunk, then the probe; negative = default).  Results do not depend on it."""
+    _capi.check(_capi.lib().tclip_debug_set_dead_head(int(iterations)), "tclip_debug_set_dead_head")
 
 
 def debug_set_rowset_min_rows(rows=-1):

@@ -5,6 +5,8 @@ while tasks inside a batch are coupled by the MM stop test, so the batch is the 
 distributed: rank r runs batches {b : b % world == r}.  The data path needs no collective; the
 only exchange is ONE gather of the per-task results onto rank 0 (RCCL over xGMI when the
 process group is "nccl", gloo in the CPU tests)."""
+import os
+
 import torch
 import torch.distributed as dist
 
@@ -127,23 +129,55 @@ def gather_rank_values(value, device=None):
     return [float(t.item()) for t in every]
 
 
-def _node_key():
-    """a number that is the same for the ranks of one node and (practically) different across nodes: a hash of the host name
-    folded to 48 bits, exact in the float64 the ranks exchange"""
+def _fold48(text):
+    """48 bits of a string's SHA-1 as a float: exact in the float64 the ranks exchange"""
     import hashlib
+    return float(int.from_bytes(hashlib.sha1(text.encode()).digest()[:6], "big"))
+
+
+def _node_key(env=None):
+    """A number that is the same for the ranks of one node and different across nodes.  The launcher knows the node:
+    torch.distributed.run exports GROUP_RANK (the node's rank), and RANK // LOCAL_WORLD_SIZE is the same number for
+    launchers that export only those two.  Without either, a hash of the host name (which nodes or containers started
+    with one fixed --hostname would share: hence only the fallback)."""
     import socket
-    return float(int.from_bytes(hashlib.sha1(socket.gethostname().encode()).digest()[:6], "big"))
+    env = os.environ if env is None else env
+    if env.get("GROUP_RANK", "").isdigit():
+        return float(int(env["GROUP_RANK"]))
+    if env.get("RANK", "").isdigit() and env.get("LOCAL_WORLD_SIZE", "").isdigit() and int(env["LOCAL_WORLD_SIZE"]) > 0:
+        return float(int(env["RANK"]) // int(env["LOCAL_WORLD_SIZE"]))
+    return _fold48(socket.gethostname())
 
 
-def check_one_device_per_rank(device_index, device=None, node_key=None):
-    """Every rank must drive its own GPU: gathers the ranks' (node, device index) pairs and raises when two ranks OF ONE NODE
-    share a device (a launcher that did not export LOCAL_RANK, or a script that ignored it, would run N ranks on cuda:0 and
-    report N times the single-GPU rate as if it scaled).  Device indices repeat across the nodes of a multi-node job
-    (0..7 on each), so the node - a hash of its host name, `node_key` overrides it in tests - is part of the pair.
-    Returns the list of device indices by rank."""
+def _device_key(device_index):
+    """The PHYSICAL device behind a process-local index: its uuid, else its PCI address.  A launcher that gives every rank
+    one GPU through HIP_VISIBLE_DEVICES makes every rank see index 0 - on different devices; the process-local index
+    (the fallback, and what CPU tests pass) cannot tell that apart from N ranks on one GPU."""
+    try:
+        if torch.cuda.is_available() and 0 <= int(device_index) < torch.cuda.device_count():
+            p = torch.cuda.get_device_properties(int(device_index))
+            uuid = getattr(p, "uuid", None)
+            if uuid is not None and set(str(uuid)) - set("0-"):
+                return _fold48("uuid:" + str(uuid))
+            pci = [getattr(p, n, None) for n in ("pci_domain_id", "pci_bus_id", "pci_device_id")]
+            if pci[1] is not None:
+                return _fold48("pci:" + ":".join(str(v) for v in pci))
+    except Exception:
+        pass
+    return float(int(device_index))
+
+
+def check_one_device_per_rank(device_index, device=None, node_key=None, device_key=None):
+    """Every rank must drive its own GPU: gathers the ranks' (node, physical device) pairs and raises when two ranks OF ONE
+    NODE share a device (a launcher that did not export LOCAL_RANK, or a script that ignored it, would run N ranks on cuda:0
+    and report N times the single-GPU rate as if it scaled).  Devices repeat across the nodes of a multi-node job, so the
+    node (`_node_key`: the launcher's node rank, else a host-name hash) is part of the pair; the device is identified by its
+    uuid / PCI address (`_device_key`), so ranks that all see index 0 through HIP_VISIBLE_DEVICES pass when the devices
+    differ.  `node_key` / `device_key` override both in tests.  Returns the list of device indices by rank."""
     seen = [int(v) for v in gather_rank_values(float(device_index), device)]
+    keys = [int(v) for v in gather_rank_values(_device_key(device_index) if device_key is None else float(device_key), device)]
     nodes = [int(v) for v in gather_rank_values(_node_key() if node_key is None else float(node_key), device)]
-    pairs = list(zip(nodes, seen))
+    pairs = list(zip(nodes, keys))
     if len(set(pairs)) != len(pairs):
         raise RuntimeError(f"ranks share a GPU: device index per rank = {seen}" +
                            (f" (nodes {nodes})" if len(set(nodes)) > 1 else ""))
