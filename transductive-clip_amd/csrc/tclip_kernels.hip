@@ -3080,6 +3080,29 @@ static void launch_kmeans_logits(int T, hipStream_t st, const float* w, const fl
     dispatch_E<LaunchKmeansLogitsRows>(K, T, st, w, z, need, Q, K, pre, temperature, logit0);
 }
 
+// XCD-aware block -> (task, tile) mapping of the kernels whose blocks share a task's operands (round 6).  The hardware deals
+// consecutive workgroups to the eight XCDs in turn and every XCD has its own L2: with the task as the slowest grid dimension
+// the (K/64)^2 blocks of one task landed on all eight XCDs and each L2 fetched the task's u and f (2 x 119 KB at K = 397)
+// for itself.  Here the grid is one-dimensional: block L runs on XCD L % 8 and works on task 8 (L / 8 / tiles) + L % 8, tile
+// (L / 8) % tiles of it - the blocks of ONE task go to ONE XCD, whose L2 holds the operands once.
+// TCLIP_XCD_MAP=0 (A/B builds): the plain order, task slowest.
+#ifndef TCLIP_XCD_MAP
+#define TCLIP_XCD_MAP 1
+#endif
+constexpr int kXcds = 8;
+struct TaskTile { int t, bx, by; };
+__device__ __forceinline__ TaskTile task_tile_of_block(int nx, int ny) {
+    const int per_task = nx * ny;
+#if TCLIP_XCD_MAP
+    const int slot = blockIdx.x / kXcds, xcd = blockIdx.x % kXcds;
+    const int t = (slot / per_task) * kXcds + xcd, inner = slot % per_task;
+#else
+    const int t = blockIdx.x / per_task, inner = blockIdx.x % per_task;
+#endif
+    return TaskTile{t, inner % nx, inner / nx};                 // the caller returns at once when t >= T
+}
+static unsigned task_tile_grid(int nx, int ny, int T) { return (unsigned)((long)((T + kXcds - 1) / kXcds) * kXcds * nx * ny); }
+
 // M-step statistics / centroids / prototypes: rows whose K columns all lie in torch's cascade region
 // go through the 8-rows-per-thread kernel, the last few rows through the one-row kernel.
 // The same statistics with the task's feature columns staged ONCE per block (round 4), for the reference's 75 queries: a block
@@ -3098,11 +3121,13 @@ __global__ __launch_bounds__(64 * kColsWaves) void k_mstats_cols75(const float* 
                                                                    const float* __restrict__ cs, const uint8_t* __restrict__ live,
                                                                    const float* __restrict__ sup, const float* __restrict__ cnt, int K,
                                                                    int k_rows, int rows_per_block, float* __restrict__ y, int paddle,
-                                                                   const float* __restrict__ wc) {
+                                                                   const float* __restrict__ wc, int T, int nx, int ny) {
     __shared__ float zt[kColsQ * 64];
-    const int t = blockIdx.z, d0 = blockIdx.x * 64;
+    const TaskTile tt = task_tile_of_block(nx, ny);
+    if (tt.t >= T) return;
+    const int t = tt.t, d0 = tt.bx * 64;
     const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const int kb = blockIdx.y * rows_per_block;
+    const int kb = tt.by * rows_per_block;
     const int ke = kb + rows_per_block < k_rows ? kb + rows_per_block : k_rows;
     if (kb >= ke) return;
     {   // nothing to do for a block without a live class (block-uniform)
@@ -3189,16 +3214,173 @@ __global__ __launch_bounds__(64 * kColsWaves) void k_mstats_cols75(const float* 
     }
 }
 
+// The same statistics as a register-tiled product for tasks whose classes are (nearly) all alive - SOFT_KMEANS (round 6).
+// k_mstats_cols75 hands u to the arithmetic as wave-uniform scalar loads, eight dwords per query and eight packed
+// instructions that use them: the counters of round 5 showed its wavefronts waiting 68 % of their cycles on those loads
+// (s_load returns out of order, so every wait is for ALL of them, and the LDS reads of the feature column share the
+// counter), VALU 55 % busy.  Here a wavefront owns a 32 x 32 tile of outputs, lane (jr, cc) the 4 classes x 4 columns at
+// (4 jr, 4 cc): per query one 16-byte LDS read of u[q, 4 classes] and one of f[q, 4 columns] feed sixteen packed
+// instructions (two reads per 16 where the column kernel needs one scalar load and one read per 8), both operands
+// arrive through the in-order LDS queue, and nothing is wave-uniform.  A block of four wavefronts stages
+// u[t, 0..74, 64 classes] and f[t, 0..74, 64 columns] (38 KB) once.
+// Same operations in the same order per output as k_mstats_cols75 / k_mstats_rows: products u f added in query order, a0
+// dumped into a1 after every 16 queries, a0 + a1 + 0 + 0.  Rows of the cascade region only (k < k_rows).
+// It does the work of a whole tile for any live class in it: the host uses it only where clusters do not die in numbers
+// (SOFT_KMEANS; EM_GAUSSIAN keeps one cluster per task alive and stays with the column kernel, which skips by eight).
+// Blocks of one task share an XCD (task_tile_of_block).
+constexpr int kTileQ = 75, kTileBlock = 64;
+#ifndef TCLIP_TILE_STAGE_BOTH
+#define TCLIP_TILE_STAGE_BOTH 1
+#endif
+#ifndef TCLIP_TILE_PREFETCH
+#define TCLIP_TILE_PREFETCH 1
+#endif
+#ifndef TCLIP_TILE_WAVES
+#define TCLIP_TILE_WAVES 3
+#endif
+__global__ __launch_bounds__(256, TCLIP_TILE_WAVES) void k_mstats_tile75(const float* __restrict__ u, const float* __restrict__ f,
+                                                       const float* __restrict__ cs, const uint8_t* __restrict__ live,
+                                                       const float* __restrict__ sup, const float* __restrict__ cnt, int K, int T,
+                                                       int k_rows, int tiles_d, int tiles_k, float* __restrict__ y, int paddle) {
+    __shared__ __attribute__((aligned(16))) float zt[kTileQ * kTileBlock];
+    __shared__ __attribute__((aligned(16))) float ut[kTileQ * kTileBlock];
+    const TaskTile tt = task_tile_of_block(tiles_d, tiles_k);
+    if (tt.t >= T) return;
+    const int t = tt.t, d0 = tt.bx * kTileBlock, kb = tt.by * kTileBlock;
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    {   // staging: thread (wave, lane) moves column `lane` of queries wave, wave + 4, ... of both operands
+        const int dc = d0 + lane < K ? d0 + lane : K - 1, kc = kb + lane < K ? kb + lane : K - 1;
+        const float* fp = f + ((size_t)t * kTileQ + wave) * K + dc;
+        const float* upg = u + ((size_t)t * kTileQ + wave) * K + kc;
+        // one operand at a time: nineteen loads in flight, then their nineteen LDS writes (both operands at once were 38 registers
+        // that the accumulators' 32 and the double-buffered reads did not leave room for at four wavefronts per SIMD)
+        auto stage = [&](const float* src, float* dst) {
+            float r[19];
+#pragma unroll
+            for (int j = 0; j < 19; j++) r[j] = (j < 18 || wave < kTileQ - 72) ? src[(size_t)4 * j * K] : 0.0f;   // 4 * 18 + wave < 75
+#pragma unroll
+            for (int j = 0; j < 19; j++)
+                if (j < 18 || wave < kTileQ - 72) dst[(4 * j + wave) * kTileBlock + lane] = r[j];
+        };
+#if TCLIP_TILE_STAGE_BOTH
+        float fr[19], ur[19];
+#pragma unroll
+        for (int j = 0; j < 19; j++) {
+            const bool in = j < 18 || wave < kTileQ - 72;
+            fr[j] = in ? fp[(size_t)4 * j * K] : 0.0f;
+            ur[j] = in ? upg[(size_t)4 * j * K] : 0.0f;
+        }
+#pragma unroll
+        for (int j = 0; j < 19; j++) {
+            if (j < 18 || wave < kTileQ - 72) {
+                zt[(4 * j + wave) * kTileBlock + lane] = fr[j];
+                ut[(4 * j + wave) * kTileBlock + lane] = ur[j];
+            }
+        }
+#else
+        stage(fp, zt);
+        stage(upg, ut);
+#endif
+    }
+    __syncthreads();
+    const int kw = kb + 32 * (wave >> 1), dw = d0 + 32 * (wave & 1);       // this wavefront's 32 x 32 tile
+    if (kw >= k_rows || dw >= K) return;
+    const int jr = lane >> 3, cc = lane & 7;
+    const float* up = ut + 32 * (wave >> 1) + 4 * jr;
+    const float* zp = zt + 32 * (wave & 1) + 4 * cc;
+    f2 a0[4][2], a1[4][2];                                                  // [class][column pair]
+#pragma unroll
+    for (int i = 0; i < 4; i++) a0[i][0] = a0[i][1] = a1[i][0] = a1[i][1] = pk(0.0f);
+    // the operands of query q + 1 are requested before the sixteen packed instructions of query q (the LDS answers in order,
+    // so the wait before them is for the older pair only)
+    auto fetch = [&](int q, float4& uv, float4& fv) {
+        uv = *(const float4*)(up + q * kTileBlock);
+        fv = *(const float4*)(zp + q * kTileBlock);
+    };
+    auto apply = [&](const float4& uv, const float4& fv) {
+        const f2 f01{fv.x, fv.y}, f23{fv.z, fv.w};
+        const float uu[4] = {uv.x, uv.y, uv.z, uv.w};
+#pragma unroll
+        for (int i = 0; i < 4; i++) {
+            a0[i][0] = a0[i][0] + pk(uu[i]) * f01;
+            a0[i][1] = a0[i][1] + pk(uu[i]) * f23;
+        }
+    };
+    float4 un, fn;
+    fetch(0, un, fn);
+#pragma unroll 1
+    for (int g = 0; g < kTileQ / 16; g++) {                                 // four groups of sixteen queries, a dump after each
+#pragma unroll
+        for (int i = 0; i < 16; i++) {
+#if TCLIP_TILE_PREFETCH
+            const float4 uc = un, fc = fn;
+            fetch(16 * g + i + 1, un, fn);                                  // (query 64 after the last group: the leftovers' first)
+            apply(uc, fc);
+#else
+            float4 uc, fc;
+            fetch(16 * g + i, uc, fc);
+            apply(uc, fc);
+#endif
+        }
+#pragma unroll
+        for (int i = 0; i < 4; i++) {
+            a1[i][0] = a1[i][0] + a0[i][0]; a0[i][0] = pk(0.0f);
+            a1[i][1] = a1[i][1] + a0[i][1]; a0[i][1] = pk(0.0f);
+        }
+    }
+#pragma unroll
+    for (int q = 16 * (kTileQ / 16); q < kTileQ; q++) {                     // the last eleven
+#if TCLIP_TILE_PREFETCH
+        const float4 uc = un, fc = fn;
+        if (q + 1 < kTileQ) fetch(q + 1, un, fn);
+        apply(uc, fc);
+#else
+        float4 uc, fc;
+        fetch(q, uc, fc);
+        apply(uc, fc);
+#endif
+    }
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+        const int k = kw + 4 * jr + i;
+        if (k >= k_rows) continue;
+        const size_t row = (size_t)t * K + k;
+        if (!live[row]) continue;
+        const float c = cs[row];
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+            const int d = dw + 4 * cc + j;
+            if (d >= K) continue;
+            float s = (j & 1) ? a0[i][j >> 1].y : a0[i][j >> 1].x;
+            s += (j & 1) ? a1[i][j >> 1].y : a1[i][j >> 1].x;
+            s += 0.0f;                                  // a2, a3 of the cascade: never filled with 75 terms, but added
+            s += 0.0f;
+            if (paddle == 2) {
+                y[row * K + d] = s / c;
+            } else if (sup && paddle) {
+                y[row * K + d] = (s + sup[row * K + d]) / (c + cnt[row]);
+            } else if (sup) {
+                const float w = 1.0f / (cnt[row] + c);
+                y[row * K + d] = w * (sup[row * K + d] + s);
+            } else {
+                y[row * K + d] = s / (c < kEpsF ? kEpsF : c);
+            }
+        }
+    }
+}
+
 // KL_KMEANS's centroids (k_kl_centroids) in the same blocking: one chain of fused multiply-adds per output over the 75
 // queries in ascending order (what MKL's sgemm does for these shapes), 64 feature columns staged once per block, u as scalar
 // loads.  Q * K * K >= 400 here (K >= 8), i.e. always the fused form.
 __global__ __launch_bounds__(64 * kColsWaves) void k_kl_centroids_cols75(const float* __restrict__ u, const float* __restrict__ z,
                                                                          const float* __restrict__ cs, int K, int rows_per_block,
-                                                                         float* __restrict__ w) {
+                                                                         float* __restrict__ w, int T, int nx, int ny) {
     __shared__ float zt[kColsQ * 64];
-    const int t = blockIdx.z, d0 = blockIdx.x * 64;
+    const TaskTile tt = task_tile_of_block(nx, ny);
+    if (tt.t >= T) return;
+    const int t = tt.t, d0 = tt.bx * 64;
     const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const int kb = blockIdx.y * rows_per_block;
+    const int kb = tt.by * rows_per_block;
     const int ke = kb + rows_per_block < K ? kb + rows_per_block : K;
     if (kb >= ke) return;
     const float* ft = z + (size_t)t * kColsQ * K;
@@ -3244,12 +3426,27 @@ __global__ __launch_bounds__(64 * kColsWaves) void k_kl_centroids_cols75(const f
 }
 
 static int g_mstats_cols = -1;          // tclip_debug_set_kmeans_tile also switches this kernel (0: k_mstats_rows for every shape)
+#ifndef TCLIP_MSTATS_TILE
+#define TCLIP_MSTATS_TILE -1
+#endif
+static int g_mstats_tile = TCLIP_MSTATS_TILE;          // tclip_debug_set_kmeans_tile switches this kernel too (0: never)
 template <bool kCov>
 static void launch_mstats_mode(hipStream_t st, const float* u, const float* f, const float* cs, const uint8_t* live,
-                               const float* sup, const float* cnt, int T, int Q, int K, float* y, int paddle, const float* wc) {
+                               const float* sup, const float* cnt, int T, int Q, int K, float* y, int paddle, const float* wc,
+                               bool dense = false) {
     const long ncols = (long)K * K;
     const int full_rows = ncols >= 8 ? (int)(((ncols / 32) * 32) / K) : 0;      // rows 0 .. full_rows-1 are all-cascade
     int groups = full_rows / kMstatsRows;
+    if (!kCov && dense && Q == kTileQ && full_rows >= 32 && g_mstats_tile != 0) {
+        // nearly every class alive (the caller's word): 32 x 32 register tiles, both operands through LDS
+        const int tiles_d = (K + kTileBlock - 1) / kTileBlock, tiles_k = (full_rows + kTileBlock - 1) / kTileBlock;
+        hipLaunchKernelGGL(k_mstats_tile75, dim3(task_tile_grid(tiles_d, tiles_k, T)), dim3(256), 0, st,
+                           u, f, cs, live, sup, cnt, K, T, full_rows, tiles_d, tiles_k, y, paddle);
+        if (full_rows < K)
+            hipLaunchKernelGGL(k_mstats<kCov>, dim3((K + 63) / 64, K - full_rows, T), dim3(64), 0, st, u, f, cs, live, sup, cnt, Q, K, y,
+                               paddle, full_rows, wc);
+        return;
+    }
     if (Q == kColsQ && full_rows >= kColsChunk && g_mstats_cols != 0) {
         // the column kernel takes every row of the cascade region; enough blocks to fill the machine, at least 32 rows each
         const int dtiles = (K + 63) / 64;
@@ -3258,8 +3455,8 @@ static void launch_mstats_mode(hipStream_t st, const float* u, const float* f, c
         if (splits < 1) splits = 1;
         int rows_per_block = ((full_rows + splits - 1) / splits + kColsChunk - 1) / kColsChunk * kColsChunk;
         splits = (full_rows + rows_per_block - 1) / rows_per_block;
-        hipLaunchKernelGGL(k_mstats_cols75<kCov>, dim3(dtiles, splits, T), dim3(64 * kColsWaves), 0, st, u, f, cs, live, sup, cnt, K, full_rows,
-                           rows_per_block, y, paddle, wc);
+        hipLaunchKernelGGL(k_mstats_cols75<kCov>, dim3(task_tile_grid(dtiles, splits, T)), dim3(64 * kColsWaves), 0, st, u, f, cs, live, sup, cnt, K,
+                           full_rows, rows_per_block, y, paddle, wc, T, dtiles, splits);
         groups = full_rows / kMstatsRows;
         const int k_first = full_rows;
         if (k_first < K)
@@ -3275,9 +3472,10 @@ static void launch_mstats_mode(hipStream_t st, const float* u, const float* f, c
         hipLaunchKernelGGL(k_mstats<kCov>, dim3((K + 63) / 64, K - k_first, T), dim3(64), 0, st, u, f, cs, live, sup, cnt, Q, K, y,
                            paddle, k_first, wc);
 }
+// dense: the caller expects (nearly) every class of every task to be alive - the register-tiled kernel
 static void launch_mstats(hipStream_t st, const float* u, const float* f, const float* cs, const uint8_t* live,
-                          const float* sup, const float* cnt, int T, int Q, int K, float* y, int paddle) {
-    launch_mstats_mode<false>(st, u, f, cs, live, sup, cnt, T, Q, K, y, paddle, nullptr);
+                          const float* sup, const float* cnt, int T, int Q, int K, float* y, int paddle, bool dense = false) {
+    launch_mstats_mode<false>(st, u, f, cs, live, sup, cnt, T, Q, K, y, paddle, nullptr, dense);
 }
 // EM_GAUSSIAN_COV: s = cs / max(sum_q (w - z_q)^2 u, eps) for the rows `live` marks
 static void launch_cov_stats(hipStream_t st, const float* u, const float* z, const float* cs, const uint8_t* live,
@@ -3699,13 +3897,16 @@ static int soft_kmeans_core(const tclip_problem& p, const float* x_q, float temp
     // w_init: every centroid = u^T z / clamp(sum u)                             (soft_kmeans.py:137-149)
     hipLaunchKernelGGL(k_cluster_sizes, dim3((TK + 255) / 256), dim3(256), 0, st, (const float*)u, T, Q, K, 1, cs, live,
                        (float*)nullptr, (int32_t*)nullptr);
-    launch_mstats(st, (const float*)u, (const float*)x_q, (const float*)cs, (const uint8_t*)ones, (const float*)nullptr, (const float*)nullptr, T, Q, K, w, 0);
+    launch_mstats(st, (const float*)u, (const float*)x_q, (const float*)cs, (const uint8_t*)ones, (const float*)nullptr, (const float*)nullptr, T, Q, K, w, 0, true);
+    // SOFT_KMEANS keeps its clusters alive (every query spreads its responsibility over all of them); EM_GAUSSIAN's class-proportion
+    // term leaves a handful per task after two iterations (profiles/r05_kmeans_live_clusters.txt): only the former is "dense"
+    const bool dense = v == nullptr;
     for (int it = 0; it < p.iters; it++) {
         // w_update: live clusters get the new mean, empty ones keep their centroid   (:151-168)
         // EM_GAUSSIAN: the same pass over u also yields v of the previous iteration's v_update (v stays 0 before the first)
         hipLaunchKernelGGL(k_cluster_sizes, dim3((TK + 255) / 256), dim3(256), 0, st, (const float*)u, T, Q, K, 1, cs,
                            live, it > 0 ? v : (float*)nullptr, (int32_t*)nullptr);
-        launch_mstats(st, (const float*)u, (const float*)x_q, (const float*)cs, (const uint8_t*)live, (const float*)nullptr, (const float*)nullptr, T, Q, K, w, 0);
+        launch_mstats(st, (const float*)u, (const float*)x_q, (const float*)cs, (const uint8_t*)live, (const float*)nullptr, (const float*)nullptr, T, Q, K, w, 0, dense);
         // distances only for centroids that moved (all of them in the first iteration)
         launch_kmeans_logits(T, st, (const float*)w, x_q, (const uint8_t*)(it == 0 ? ones : live), Q, K, -0.5f,
                                            temperature, logit0);
@@ -4004,8 +4205,9 @@ int tclip_kl_kmeans_run(const tclip_problem* pp, const float* x_q, float* u, flo
             if (splits > K / (kColsWaves * kColsChunk)) splits = K / (kColsWaves * kColsChunk);
             if (splits < 1) splits = 1;
             const int rows_per_block = ((K + splits - 1) / splits + kColsChunk - 1) / kColsChunk * kColsChunk;
-            hipLaunchKernelGGL(k_kl_centroids_cols75, dim3(dtiles, (K + rows_per_block - 1) / rows_per_block, T), dim3(64 * kColsWaves), 0,
-                               st, (const float*)u, x_q, (const float*)cs, K, rows_per_block, w);
+            const int ksplits = (K + rows_per_block - 1) / rows_per_block;
+            hipLaunchKernelGGL(k_kl_centroids_cols75, dim3(task_tile_grid(dtiles, ksplits, T)), dim3(64 * kColsWaves), 0,
+                               st, (const float*)u, x_q, (const float*)cs, K, rows_per_block, w, T, dtiles, ksplits);
         } else {
             hipLaunchKernelGGL(k_kl_centroids, dim3((K + 63) / 64, (K + kMstatsRows - 1) / kMstatsRows, T), dim3(64), 0, st,
                                (const float*)u, x_q, (const float*)cs, Q, K, w);
@@ -4054,6 +4256,7 @@ int tclip_debug_set_rowset_min_rows(int32_t rows) {
 int tclip_debug_set_kmeans_tile(int32_t mode) {
     g_kmeans_tile = mode;
     g_mstats_cols = mode;
+    g_mstats_tile = mode < 0 ? TCLIP_MSTATS_TILE : mode;
     return TCLIP_OK;
 }
 
