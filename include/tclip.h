@@ -305,8 +305,8 @@ int tclip_debug_set_split_keep_placement(int32_t on);
  * restores the default.  Process-wide; results do not depend on it. */
 int tclip_debug_set_probe_chunks(int32_t chunks);
 
-/* Rows that have just died run only their first `iterations` MM iterations (default 16) before an early probe looks for
- * the limit cycle from there on (a second snapshot 32 iterations later finds rows that were still approaching their cycle);
+/* Rows that have just died run only their first `iterations` MM iterations (default 12) before an early probe looks for
+ * the limit cycle from there on (further snapshots 8 and 32 iterations later find rows that were still approaching their cycle);
  * rows it cannot finish take the path above from the start.  For tests: 0 disables the early probe (the path above for
  * every dead row), negative restores the default, more than 18 is refused (TCLIP_ERR_ARG).  Also off while
  * tclip_debug_set_probe_chunks(0) is in force.  Process-wide; results do not depend on it. */

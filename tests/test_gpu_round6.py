@@ -1,7 +1,7 @@
 """GPU (round 6): the early limit-cycle probe of freshly dead rows (k_mm_probe_head) is an exact shortcut.
 
 A row that has just died used to run the whole first chunk (51 iterations) before k_mm_probe looked for its limit cycle; it now
-runs TCLIP_DEAD_HEAD = 16 iterations and the probe searches from there (a second snapshot after 32 more), filling every checkpoint of the
+runs TCLIP_DEAD_HEAD = 12 iterations and the probe searches from there (further snapshots 8 and 32 iterations on), filling every checkpoint of the
 row from the cycle it finds.  The cached stop-test terms decide when a BATCH stops (em_dirichlet.py:169-175), so a wrong entry
 shows up as a different MM count - in the outer iteration in which the row dies or in any later one - and from there in alpha."""
 import numpy as np
@@ -24,7 +24,7 @@ def _run(x, B, K, iters, iter_mm, hard):
                                                       (129, 5, 2, 5, 120, False), (257, 4, 1, 4, 1000, False), (897, 3, 1, 4, 500, False),
                                                       (100, 7, 1, 4, 60, False), (100, 7, 1, 4, 101, False)])
 def test_early_dead_row_probe_is_invisible(K, N, B, iters, iter_mm, hard):
-    """default (16 head iterations), other head lengths (4 and 1: most rows are still approaching their cycle when the probe starts
+    """default (12 head iterations), other head lengths (4 and 1: most rows are still approaching their cycle when the probe starts
     and are found through its second snapshot or handed back to the old path; 18: the longest allowed), the old path (0) and
     no probe at all: same bits"""
     from tclip_amd import engine, synth
@@ -32,7 +32,7 @@ def test_early_dead_row_probe_is_invisible(K, N, B, iters, iter_mm, hard):
     x = x_q.cuda()
     runs = {}
     try:
-        for head in (-1, 0, 4, 18, 1):
+        for head in (-1, 0, 4, 18, 1, 16):
             engine.debug_set_dead_head(head)
             runs[head] = _run(x, B, K, iters, iter_mm, hard)
         engine.debug_set_dead_head(-1)
@@ -52,7 +52,7 @@ def test_early_dead_row_probe_is_invisible(K, N, B, iters, iter_mm, hard):
 
 
 def test_early_probe_takes_the_dead_rows_off_the_first_chunk():
-    """what ran: with the early probe the dead-row kernel's share of a K = 1000 call shrinks (16 + period iterations per death
+    """what ran: with the early probe the dead-row kernel's share of a K = 1000 call shrinks (12 + period iterations per death
     instead of 51 + period) - the per-kernel times of the torch profiler, same problem, both paths"""
     from torch.profiler import ProfilerActivity, profile
     from tclip_amd import engine, synth
@@ -79,5 +79,5 @@ def test_early_probe_takes_the_dead_rows_off_the_first_chunk():
     assert torch.equal(r0.alpha, r1.alpha) and torch.equal(r0.mm_iters, r1.mm_iters)
     assert "k_mm_probe_head" in new and "k_mm_probe_head" not in old
     t_old, t_new = sum(old.values()), sum(new.values())
-    print(f"dead-row kernels: {t_old:.0f} us (whole first chunk + probe) -> {t_new:.0f} us (16 iterations + early probe): {old} -> {new}")
+    print(f"dead-row kernels: {t_old:.0f} us (whole first chunk + probe) -> {t_new:.0f} us (12 iterations + early probe): {old} -> {new}")
     assert t_new < 0.8 * t_old

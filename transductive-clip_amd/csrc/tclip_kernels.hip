@@ -626,6 +626,69 @@ __device__ __forceinline__ void mm_apply_updates(float (&beta)[E], const RowY<E,
     }
 }
 
+// Phase C for a wavefront that queued NOTHING for the large-argument lgamma in this iteration (every a + 1 of its rows is
+// below 2.3 - wave-uniform, known from phase A's count): the same values as mm_apply_updates, without the per-pair ballots,
+// ranks and LDS pick-up of the queue, without the stand-in argument of the polynomial lgamma and with the first eight steps
+// of digamma's recurrence unmasked (pk_mm_update_stage1_small).  In the first outer iteration every parameter starts at 1:
+// all wavefronts take this path for the first iterations, 44 % of the K = 1000 rows still do after 50 (HISTORY.md section 8);
+// dead rows, whose parameters collapse to ~0.14 within a dozen iterations, always do.
+#ifndef TCLIP_MM_SMALL_PATH
+#define TCLIP_MM_SMALL_PATH 1
+#endif
+template <int E, int G = kGroup>
+__device__ __forceinline__ void mm_apply_updates_small(float (&beta)[E], const RowY<E, G>& yv, int K, int lane, float psi_s,
+                                                       const LogTabEntry* tab, bool measure, double& num, double& den) {
+    const int n_full = full_registers<E, G>(K);
+    constexpr bool kYLocal = !RowY<E, G>::kInRegs;
+    float yl[kYLocal ? E : 1];
+    if constexpr (kYLocal) yv.fetch_all(yl);
+    auto y_of = [&](int e) { if constexpr (kYLocal) return yl[e]; else return yv.get(e); };
+    auto finish = [&](int p, const PkUpdateStage& st) {
+        const int e = 2 * p;
+        const f2 a{beta[e], beta[e + 1]};
+        const f2 nb = pk_mm_update_stage2(st);
+        const bool full = e + 1 < n_full;
+        const bool ok0 = full || elem_of<E, G>(e, lane) < K, ok1 = full || elem_of<E, G>(e + 1, lane) < K;
+        if (measure) {
+            const double d0 = (double)nb.x - (double)a.x, d1 = (double)nb.y - (double)a.y;
+            if (ok0) { num += d0 * d0; den += (double)a.x * (double)a.x; }
+            if (ok1) { num += d1 * d1; den += (double)a.y * (double)a.y; }
+        }
+        if (full) {
+            beta[e] = nb.x;
+            beta[e + 1] = nb.y;
+        } else {
+            beta[e] = ok0 ? nb.x : 0.0f;
+            beta[e + 1] = ok1 ? nb.y : 0.0f;
+        }
+    };
+    PkUpdateStage pending;
+#pragma unroll
+    for (int p = 0; p < E / 2; p++) {
+        const int e = 2 * p;
+        const PkUpdateStage st = pk_mm_update_stage1_small(f2{beta[e], beta[e + 1]}, f2{y_of(e), y_of(e + 1)}, pk(psi_s), tab);
+        if (p > 0) finish(p - 1, pending);
+        pending = st;
+    }
+    if (E / 2 > 0) finish(E / 2 - 1, pending);
+    if (E & 1) {
+        constexpr int e = E - 1;
+        const float a = beta[e];
+        const float x1 = a + 1.0f;
+        bool sure;
+        float lg = lgamma_sleef_1_23_f64(x1, sure);
+        if (__builtin_expect(__builtin_amdgcn_ballot_w64(!sure) != 0ull, 0)) lg = sure ? lg : lgamma_sleef_05_23(x1);
+        const float nb = mm_update_algebra(a, y_of(e), psi_s, digamma_xp1(a, tab), lg);
+        const bool ok = elem_of<E, G>(e, lane) < K;
+        if (measure && ok) {
+            const double df = (double)nb - (double)a;
+            num += df * df;
+            den += (double)a * (double)a;
+        }
+        beta[e] = ok ? nb : 0.0f;
+    }
+}
+
 // Registers of an MM kernel instantiation that lie inside the row - and inside the 4-way interleaved part of torch's row
 // sum - for EVERY row length the instantiation is launched for (launch_mm: the smallest E that covers K, so at most
 // three registers of slack, the fourth for the upper half of the 64-lane layout, which starts at K = 897).
@@ -714,7 +777,8 @@ __device__ __forceinline__ void mm_iterate(float (&beta)[E], const RowY<E, G>& y
     }
     __builtin_amdgcn_wave_barrier();
     // phase C: per element digamma, cheap lgamma branch, pick-up, algebra
-    mm_apply_updates<E, G>(beta, yv, K, lane, psi_s, tab, queue, 0, measure, num, den);
+    if (TCLIP_MM_SMALL_PATH && n_big == 0) mm_apply_updates_small<E, G>(beta, yv, K, lane, psi_s, tab, measure, num, den);
+    else mm_apply_updates<E, G>(beta, yv, K, lane, psi_s, tab, queue, 0, measure, num, den);
     __builtin_amdgcn_wave_barrier();
 }
 
@@ -800,23 +864,27 @@ __global__ __launch_bounds__(256, (E > 16 ? TCLIP_MM_WAVES_LARGE : TCLIP_MM_WAVE
 }
 
 // Early limit-cycle probe (round 6) for rows that have JUST died: k_mm_live<.., true> has run only the first `a.l0`
-// iterations (TCLIP_DEAD_HEAD, not the whole first chunk) and left b_{l0} in `beta_dead`.
+// iterations (TCLIP_DEAD_HEAD = 12, not the whole first chunk) and left b_{l0} in `beta_dead`.
 // Measured on the reference's trajectories (scripts/dead_row_cycles.py, CPU oracle, the alpha rows of a task after its first
 // outer iteration): a dead row is ON its cycle after 8..15 iterations at K = 100 (median 10; periods 1, 2, 4) and after
 // 8..28 at K = 1000 (median 11, 99 % within 16; periods 20 (75 %), 5, 4, 8) - so the 51 iterations of chunk 0 that
 // k_mm_probe waits for are mostly spent going round the cycle.  Here the probe starts at iteration l0, measures the pair
-// (||b'-b||^2, ||b||^2) of EVERY iteration it executes (cyc[j]: iteration l0 + j) and compares the state with a snapshot:
-// b_{l0} itself for the first 32 iterations, the state after them from then on (a snapshot taken before the row reached its
-// cycle is never met again, a later one is; the first version renewed it after 4, 8, 16 and 32 iterations and met the
-// 20-iteration cycles of K = 1000 only through the last one, after 52 iterations - a snapshot must stand for a whole period).
+// (||b'-b||^2, ||b||^2) of EVERY iteration it executes (cyc[j]: iteration l0 + j) and compares the state with two snapshots:
+// b_{l0} itself for the first 32 iterations and the state after them from then on, and the state 8 iterations in (kept in
+// the row's y, which a dead row does not use).  A snapshot taken before the row reached its cycle is never met again, a later
+// one is - and it must stand for a whole period (the first version renewed ONE snapshot after 4, 8, 16 and 32 iterations and met
+// the 20-iteration cycles of K = 1000 only through the last one, after 52 iterations); the second snapshot finds the rows whose
+// transient is a little longer than l0 (8 % at K = 397, hard) after 8 + p iterations instead of 32 + p.
 // State s_{j+1} == snapshot s_js: the trajectory is periodic from iteration l0 + js on
 // with period p = j + 1 - js, and the pair of iteration l >= l0 + js is cyc[js + (l - l0 - js) mod p] - every checkpoint of
 // the row (l = 50, 100, ...; l0 + 32 <= 50 is checked on the host) is filled and the row is done, exactly as if it had run.
+// Head lengths 12 / 14 / 16 measured (dead-row kernels of one call, us; K = 1000 | 397 hard | 100): 17 717 | 7 199 | 1 029,
+// 18 680 | 7 232 | 1 059, 19 554 | 7 015 | 1 039 - 12 it is (scripts/gpu_dead_trace.py).
 // No cycle within kMaxCycle iterations, or a row whose cache is partly filled (a batch that stopped early): the row goes to
 // the list `next_rows`, which the host hands to the old path (k_mm_live<.., true> over the whole chunk from alpha, then
 // k_mm_probe) - nothing is assumed about such a row.
 #ifndef TCLIP_DEAD_HEAD
-#define TCLIP_DEAD_HEAD 16
+#define TCLIP_DEAD_HEAD 12
 #endif
 template <int E, int G>
 __global__ __launch_bounds__(256, (E > 16 ? TCLIP_MM_WAVES_LARGE : TCLIP_MM_WAVES_SMALL)) void k_mm_probe_head(MMArgs a) {
@@ -837,7 +905,9 @@ __global__ __launch_bounds__(256, (E > 16 ? TCLIP_MM_WAVES_LARGE : TCLIP_MM_WAVE
             if (lane == 0) a.next_rows[atomicAdd(a.next_count, 1)] = row;
             continue;
         }
-        float* ref = a.beta_dead + (size_t)row * K;                // b_{l0}; overwritten by the later snapshots
+        float* ref = a.beta_dead + (size_t)row * K;                // b_{l0}; replaced by the state 32 iterations on
+        float* ref8 = const_cast<float*>(a.y) + (size_t)row * K;   // second snapshot, 8 iterations on: the y row of a dead row is
+                                                                   // never read (y = -10) nor written by the M-step statistics
         float beta[E];
         RowY<E, G> yv;
         yv.load(nullptr, lane, K);
@@ -846,37 +916,51 @@ __global__ __launch_bounds__(256, (E > 16 ? TCLIP_MM_WAVES_LARGE : TCLIP_MM_WAVE
             const int d = elem_of<E, G>(e, lane);
             beta[e] = d < K ? ref[d] : 0.0f;
         }
-        int period = 0, js = 0;
+        int period = 0, js = 0, base = 0;
+        bool have8 = false;
+        constexpr unsigned long long kAll = G == 64 ? ~0ull : (1ull << (G & 63)) - 1ull;
+        const int shift = (threadIdx.x & 63) & ~(G - 1);                                          // this group's lanes in a ballot
         for (int j = 0; j < kMaxCycle && period == 0; j++) {
             double pn = 0.0, pd = 0.0;
             mm_iterate<E, G>(beta, yv, K, lane, tab, queue, true, pn, pd);
             pn = group_sum_f64_g<G>(pn);
             pd = group_sum_f64_g<G>(pd);
             if (lane == 0) { cyc[group][j][0] = pn; cyc[group][j][1] = pd; }
-            bool same = true;
+            bool same = true, same8 = have8;
 #pragma unroll
             for (int e = 0; e < E; e++) {
                 const int d = elem_of<E, G>(e, lane);
                 if (d < K) same = same && (beta[e] == ref[d]);
             }
-            const unsigned long long bal = __ballot(same);
-            constexpr unsigned long long kAll = G == 64 ? ~0ull : (1ull << (G & 63)) - 1ull;
-            const unsigned long long mine = (bal >> ((threadIdx.x & 63) & ~(G - 1))) & kAll;      // this group's lanes
-            if (mine == kAll) {
-                period = j + 1 - js;
-            } else if (j + 1 == 32) {                                                              // a new snapshot: s_{j+1}
-                js = j + 1;
+            if (have8) {
 #pragma unroll
                 for (int e = 0; e < E; e++) {
                     const int d = elem_of<E, G>(e, lane);
-                    if (d < K) ref[d] = beta[e];
+                    if (d < K) same8 = same8 && (beta[e] == ref8[d]);
                 }
+            }
+            const bool hit = ((__ballot(same) >> shift) & kAll) == kAll, hit8 = ((__ballot(same8) >> shift) & kAll) == kAll;
+            if (hit) {
+                period = j + 1 - js;
+                base = js;
+            } else if (have8 && hit8) {
+                period = j + 1 - 8;
+                base = 8;
+            } else if (j + 1 == 8 || j + 1 == 32) {                                                // a new snapshot: s_{j+1}
+                float* dst = j + 1 == 8 ? ref8 : ref;
+#pragma unroll
+                for (int e = 0; e < E; e++) {
+                    const int d = elem_of<E, G>(e, lane);
+                    if (d < K) dst[d] = beta[e];
+                }
+                if (j + 1 == 8) have8 = true;
+                else js = 32;
             }
         }
         if (period && lane == 0) {
             for (int m = 0; m < a.n_checks; m++) {
                 const int t = 50 * (m + 1) - a.l0;                  // cyc index of the checkpoint's iteration, were the window long enough
-                const int j = js + (t - js) % period;
+                const int j = base + (t - base) % period;
                 double* c = a.cache + ((size_t)row * a.n_checks + m) * 2;
                 c[0] = cyc[group][j][0];
                 c[1] = cyc[group][j][1];
@@ -999,6 +1083,14 @@ __device__ __forceinline__ void mm_iterate_block(float (&beta)[R][E], const RowY
         ctl->psi[turn & 1][lane64] = digamma_pos_f32(ctl->rowsum[turn & 1][lane64], tab);
     __syncthreads();
     // phase C: per element digamma, cheap lgamma branch, pick-up, algebra
+    if (TCLIP_MM_SMALL_PATH && base[R] == 0) {                   // nothing of this wavefront's rows is in the queue (wave-uniform)
+#pragma unroll
+        for (int r = 0; r < R; r++)
+            if (active[r])
+                mm_apply_updates_small<E, G>(beta[r], yv[r], K, lane, ctl->psi[turn & 1][r * kGroups + (threadIdx.x / G)], tab,
+                                             measure, num[r], den[r]);
+        return;
+    }
 #pragma unroll
     for (int r = 0; r < R; r++)
         if (active[r])

@@ -313,6 +313,27 @@ __device__ __forceinline__ PkUpdateStage pk_mm_update_stage1(f2 a, f2 y, f2 psi_
     const f2 t = pk_t_of(lg1, psi1 * a);
     return pk_mm_update_stage1_core<true>(a, y, t.x, t.y, psi1 - psi_s);
 }
+// stage 1 for two parameters whose arguments a + 1 BOTH lie below 2.3 (the caller's wave-uniform knowledge: nothing of the
+// wavefront's rows is queued for the large-argument lgamma) - what pk_mm_update_stage1 computes for such a pair, without what
+// the general form spends on the other case: the first eight steps of digamma's recurrence are always taken (a + 1 + 7 < 10:
+// no step masks; the class-A pass of the split kernel relies on the same fact), the polynomial lgamma needs no stand-in
+// argument and nothing is picked up from the queue.
+__device__ __forceinline__ PkUpdateStage pk_mm_update_stage1_small(f2 a, f2 y, f2 psi_s, const LogTabEntry* tab) {
+    const f2 x1 = a + pk(1.0f);
+    const f2 lg1 = pk_lgamma_sleef_1_23(x1);
+    f2 xr = x1, acc = pk(0.0f);
+#pragma unroll
+    for (int k = 0; k < 8; k++) {
+        acc = acc - pk_rcp_rn(xr);
+        xr = xr + pk(1.0f);
+    }
+    const f2 m{below10_f32(xr.x), below10_f32(xr.y)};
+    acc = pk_fma(-m, pk_rcp_rn(xr), acc);
+    xr = xr + m;
+    const f2 psi1 = pk_digamma_after_rec(xr, acc, tab);
+    const f2 t = pk_t_of(lg1, psi1 * a);
+    return pk_mm_update_stage1_core<true>(a, y, t.x, t.y, psi1 - psi_s);
+}
 __device__ __forceinline__ f2 pk_mm_update_stage2(const PkUpdateStage& st) {
     const f2 yr{rsqrt14_from_entry(f32_bits(st.delta.x), st.t0), rsqrt14_from_entry(f32_bits(st.delta.y), st.t1)};
     const f2 s = st.delta * yr;
