@@ -168,17 +168,19 @@ def _device_key(device_index):
 
 
 def check_one_device_per_rank(device_index, device=None, node_key=None, device_key=None):
-    """Every rank must drive its own GPU: gathers the ranks' (node, physical device) pairs and raises when two ranks OF ONE
-    NODE share a device (a launcher that did not export LOCAL_RANK, or a script that ignored it, would run N ranks on cuda:0
-    and report N times the single-GPU rate as if it scaled).  Devices repeat across the nodes of a multi-node job, so the
-    node (`_node_key`: the launcher's node rank, else a host-name hash) is part of the pair; the device is identified by its
-    uuid / PCI address (`_device_key`), so ranks that all see index 0 through HIP_VISIBLE_DEVICES pass when the devices
-    differ.  `node_key` / `device_key` override both in tests.  Returns the list of device indices by rank."""
+    """Every rank must drive its own GPU: gathers the ranks' (node, device index, physical device) triples and raises when two
+    ranks OF ONE NODE hold the same one (a launcher that did not export LOCAL_RANK, or a script that ignored it, would run N
+    ranks on cuda:0 and report N times the single-GPU rate as if it scaled).  Devices repeat across the nodes of a multi-node
+    job, so the node (`_node_key`: the launcher's node rank, else a host-name hash) is part of the triple; the physical device
+    (`_device_key`: uuid / PCI address) lets ranks that all see index 0 through HIP_VISIBLE_DEVICES pass when the devices
+    differ, and the index stays in so that a runtime which reported ONE uuid for all its devices could not make a correct job
+    fail - the check errs on the side of running.  `node_key` / `device_key` override both in tests.
+    Returns the list of device indices by rank."""
     seen = [int(v) for v in gather_rank_values(float(device_index), device)]
     keys = [int(v) for v in gather_rank_values(_device_key(device_index) if device_key is None else float(device_key), device)]
     nodes = [int(v) for v in gather_rank_values(_node_key() if node_key is None else float(node_key), device)]
-    pairs = list(zip(nodes, keys))
-    if len(set(pairs)) != len(pairs):
+    triples = list(zip(nodes, seen, keys))
+    if len(set(triples)) != len(triples):
         raise RuntimeError(f"ranks share a GPU: device index per rank = {seen}" +
                            (f" (nodes {nodes})" if len(set(nodes)) > 1 else ""))
     return seen
