@@ -2917,7 +2917,7 @@ static hipEvent_t prof_event() {
 constexpr int kDecideSlices = 64;     // blocks per batch in the first stage of the stop test (large batches)
 struct Layout {
     size_t logz, y, alpha_old, beta_dead, sup, cnt, cs, live, rowc, logit0, cache, cache_len, rowpart, mm_rows,
-        mm_rows2, mm_rows3, dead_counts, live_rows, counts, flags, stop, ratio, dpart, total;
+        mm_rows2, mm_rows3, dead_counts, cls, n_live, live_rows, counts, flags, stop, ratio, dpart, total;
     int n_checks;
 };
 
@@ -2948,6 +2948,8 @@ static Layout make_layout(const tclip_problem& p) {
     L.mm_rows2 = take(zs ? T * K * 4 : 0);
     L.mm_rows3 = take(zs ? T * K * 4 : 0);                    // rows the early probe hands back to the old dead-row path
     L.dead_counts = take(((size_t)n_chunks_of(p.iter_mm) + 3) * 4);    // [chunk] + one spare + [n_chunks + 2]: length of mm_rows3
+    L.cls = take(zs ? T * K * 2 : 0);                         // compacted lists of live classes (k_live_class_lists)
+    L.n_live = take(zs ? T * 4 : 0);
     L.live_rows = take(T * K * 4);
     L.counts = take(256);
     L.flags = take(256);
@@ -3306,6 +3308,37 @@ __global__ __launch_bounds__(64 * kColsWaves) void k_mstats_cols75(const float* 
     }
 }
 
+// Compacted list of the live classes of every task (EM-Dirichlet's M-step statistics, zero-shot): cls[t][0 .. n_live[t]) = the
+// classes k < k_rows with live[t, k], ascending; one block per task.  After the first outer iteration ~5 % of a task's classes
+// are alive (47 of 1000 on the bench's tasks, 28-43 of 397 in hard mode) and k_mstats_cols75, which skips dead classes by
+// chunks of eight, still walked a third to a half of its chunks; k_mstats_tile75 takes this list and works on n_live / 64
+// tiles of classes.
+__global__ __launch_bounds__(256) void k_live_class_lists(const uint8_t* __restrict__ live, int K, int k_rows,
+                                                          int16_t* __restrict__ cls, int32_t* __restrict__ n_live) {
+    __shared__ int wave_count[4];
+    const int t = blockIdx.x, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const uint8_t* lt = live + (size_t)t * K;
+    int16_t* out = cls + (size_t)t * K;
+    int base = 0;
+    for (int k0 = 0; k0 < k_rows; k0 += 256) {                     // block-uniform trip count
+        const int k = k0 + threadIdx.x;
+        const bool alive = k < k_rows && lt[k] != 0;
+        const unsigned long long m = __builtin_amdgcn_ballot_w64(alive);
+        if (lane == 0) wave_count[wave] = __popcll(m);
+        __syncthreads();
+        int before = 0, total = 0;
+#pragma unroll
+        for (int w = 0; w < 4; w++) {
+            before += w < wave ? wave_count[w] : 0;
+            total += wave_count[w];
+        }
+        if (alive) out[base + before + lanes_below(m)] = (int16_t)k;
+        base += total;
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) n_live[t] = base;
+}
+
 // The same statistics as a register-tiled product for tasks whose classes are (nearly) all alive - SOFT_KMEANS (round 6).
 // k_mstats_cols75 hands u to the arithmetic as wave-uniform scalar loads, eight dwords per query and eight packed
 // instructions that use them: the counters of round 5 showed its wavefronts waiting 68 % of their cycles on those loads
@@ -3333,27 +3366,26 @@ constexpr int kTileQ = 75, kTileBlock = 64;
 __global__ __launch_bounds__(256, TCLIP_TILE_WAVES) void k_mstats_tile75(const float* __restrict__ u, const float* __restrict__ f,
                                                        const float* __restrict__ cs, const uint8_t* __restrict__ live,
                                                        const float* __restrict__ sup, const float* __restrict__ cnt, int K, int T,
-                                                       int k_rows, int tiles_d, int tiles_k, float* __restrict__ y, int paddle) {
+                                                       int k_rows, int tiles_d, int tiles_k, float* __restrict__ y, int paddle,
+                                                       const int16_t* __restrict__ cls, const int32_t* __restrict__ n_live) {
     __shared__ __attribute__((aligned(16))) float zt[kTileQ * kTileBlock];
     __shared__ __attribute__((aligned(16))) float ut[kTileQ * kTileBlock];
+    __shared__ int slot_class[kTileBlock];                      // the class behind slot kb + c of this block (-1: none)
     const TaskTile tt = task_tile_of_block(tiles_d, tiles_k);
     if (tt.t >= T) return;
     const int t = tt.t, d0 = tt.bx * kTileBlock, kb = tt.by * kTileBlock;
+    // cls: the block's 64 class slots are entries kb .. kb + 63 of the task's list of live classes (k_live_class_lists), which
+    // has n_slots entries; without a list slot i is class i and there are k_rows of them
+    const int n_slots = cls ? n_live[t] : k_rows;
+    if (kb >= n_slots) return;                                  // block-uniform: a tile of classes beyond the list
     const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     {   // staging: thread (wave, lane) moves column `lane` of queries wave, wave + 4, ... of both operands
-        const int dc = d0 + lane < K ? d0 + lane : K - 1, kc = kb + lane < K ? kb + lane : K - 1;
+        int kc = kb + lane < n_slots ? kb + lane : n_slots - 1;  // slots beyond the list repeat its last class (their outputs are skipped)
+        if (cls) kc = cls[(size_t)t * K + kc];
+        if (wave == 0) slot_class[lane] = kb + lane < n_slots ? kc : -1;
+        const int dc = d0 + lane < K ? d0 + lane : K - 1;
         const float* fp = f + ((size_t)t * kTileQ + wave) * K + dc;
         const float* upg = u + ((size_t)t * kTileQ + wave) * K + kc;
-        // one operand at a time: nineteen loads in flight, then their nineteen LDS writes (both operands at once were 38 registers
-        // that the accumulators' 32 and the double-buffered reads did not leave room for at four wavefronts per SIMD)
-        auto stage = [&](const float* src, float* dst) {
-            float r[19];
-#pragma unroll
-            for (int j = 0; j < 19; j++) r[j] = (j < 18 || wave < kTileQ - 72) ? src[(size_t)4 * j * K] : 0.0f;   // 4 * 18 + wave < 75
-#pragma unroll
-            for (int j = 0; j < 19; j++)
-                if (j < 18 || wave < kTileQ - 72) dst[(4 * j + wave) * kTileBlock + lane] = r[j];
-        };
 #if TCLIP_TILE_STAGE_BOTH
         float fr[19], ur[19];
 #pragma unroll
@@ -3370,13 +3402,23 @@ __global__ __launch_bounds__(256, TCLIP_TILE_WAVES) void k_mstats_tile75(const f
             }
         }
 #else
+        // one operand at a time: nineteen loads in flight, then their nineteen LDS writes (both operands at once were 38 registers
+        // that the accumulators' 32 and the double-buffered reads did not leave room for at four wavefronts per SIMD)
+        auto stage = [&](const float* src, float* dst) {
+            float r[19];
+#pragma unroll
+            for (int j = 0; j < 19; j++) r[j] = (j < 18 || wave < kTileQ - 72) ? src[(size_t)4 * j * K] : 0.0f;   // 4 * 18 + wave < 75
+#pragma unroll
+            for (int j = 0; j < 19; j++)
+                if (j < 18 || wave < kTileQ - 72) dst[(4 * j + wave) * kTileBlock + lane] = r[j];
+        };
         stage(fp, zt);
         stage(upg, ut);
 #endif
     }
     __syncthreads();
-    const int kw = kb + 32 * (wave >> 1), dw = d0 + 32 * (wave & 1);       // this wavefront's 32 x 32 tile
-    if (kw >= k_rows || dw >= K) return;
+    const int kw = kb + 32 * (wave >> 1), dw = d0 + 32 * (wave & 1);       // this wavefront's 32 x 32 tile (kw: its first slot)
+    if (kw >= n_slots || dw >= K) return;
     const int jr = lane >> 3, cc = lane & 7;
     const float* up = ut + 32 * (wave >> 1) + 4 * jr;
     const float* zp = zt + 32 * (wave & 1) + 4 * cc;
@@ -3434,8 +3476,8 @@ __global__ __launch_bounds__(256, TCLIP_TILE_WAVES) void k_mstats_tile75(const f
     }
 #pragma unroll
     for (int i = 0; i < 4; i++) {
-        const int k = kw + 4 * jr + i;
-        if (k >= k_rows) continue;
+        const int k = slot_class[32 * (wave >> 1) + 4 * jr + i];
+        if (k < 0) continue;
         const size_t row = (size_t)t * K + k;
         if (!live[row]) continue;
         const float c = cs[row];
@@ -3525,15 +3567,17 @@ static int g_mstats_tile = TCLIP_MSTATS_TILE;          // tclip_debug_set_kmeans
 template <bool kCov>
 static void launch_mstats_mode(hipStream_t st, const float* u, const float* f, const float* cs, const uint8_t* live,
                                const float* sup, const float* cnt, int T, int Q, int K, float* y, int paddle, const float* wc,
-                               bool dense = false) {
+                               bool dense = false, int16_t* cls = nullptr, int32_t* n_live = nullptr) {
     const long ncols = (long)K * K;
     const int full_rows = ncols >= 8 ? (int)(((ncols / 32) * 32) / K) : 0;      // rows 0 .. full_rows-1 are all-cascade
     int groups = full_rows / kMstatsRows;
-    if (!kCov && dense && Q == kTileQ && full_rows >= 32 && g_mstats_tile != 0) {
-        // nearly every class alive (the caller's word): 32 x 32 register tiles, both operands through LDS
+    if (!kCov && (dense || cls) && Q == kTileQ && full_rows >= 32 && g_mstats_tile != 0) {
+        // 32 x 32 register tiles, both operands through LDS: over all classes where (nearly) every class is alive (the caller's
+        // word), over the compacted list of the live ones where the caller provides room for it (cls, n_live)
         const int tiles_d = (K + kTileBlock - 1) / kTileBlock, tiles_k = (full_rows + kTileBlock - 1) / kTileBlock;
+        if (cls) hipLaunchKernelGGL(k_live_class_lists, dim3(T), dim3(256), 0, st, live, K, full_rows, cls, n_live);
         hipLaunchKernelGGL(k_mstats_tile75, dim3(task_tile_grid(tiles_d, tiles_k, T)), dim3(256), 0, st,
-                           u, f, cs, live, sup, cnt, K, T, full_rows, tiles_d, tiles_k, y, paddle);
+                           u, f, cs, live, sup, cnt, K, T, full_rows, tiles_d, tiles_k, y, paddle, (const int16_t*)cls, (const int32_t*)n_live);
         if (full_rows < K)
             hipLaunchKernelGGL(k_mstats<kCov>, dim3((K + 63) / 64, K - full_rows, T), dim3(64), 0, st, u, f, cs, live, sup, cnt, Q, K, y,
                                paddle, full_rows, wc);
@@ -3565,9 +3609,11 @@ static void launch_mstats_mode(hipStream_t st, const float* u, const float* f, c
                            paddle, k_first, wc);
 }
 // dense: the caller expects (nearly) every class of every task to be alive - the register-tiled kernel
+// cls / n_live: room for the compacted lists of live classes ([T, K] int16, [T] int32) - the tile kernel over those lists
 static void launch_mstats(hipStream_t st, const float* u, const float* f, const float* cs, const uint8_t* live,
-                          const float* sup, const float* cnt, int T, int Q, int K, float* y, int paddle, bool dense = false) {
-    launch_mstats_mode<false>(st, u, f, cs, live, sup, cnt, T, Q, K, y, paddle, nullptr, dense);
+                          const float* sup, const float* cnt, int T, int Q, int K, float* y, int paddle, bool dense = false,
+                          int16_t* cls = nullptr, int32_t* n_live = nullptr) {
+    launch_mstats_mode<false>(st, u, f, cs, live, sup, cnt, T, Q, K, y, paddle, nullptr, dense, cls, n_live);
 }
 // EM_GAUSSIAN_COV: s = cs / max(sum_q (w - z_q)^2 u, eps) for the rows `live` marks
 static void launch_cov_stats(hipStream_t st, const float* u, const float* z, const float* cs, const uint8_t* live,
@@ -3667,7 +3713,10 @@ static int enqueue_batches(const tclip_problem& p, const RowSrc& q_src, const Ro
         // ---- M-step statistics
         hipLaunchKernelGGL(k_cluster_sizes, dim3((TK + 255) / 256), dim3(256), 0, st, (const float*)u, T, Q, K, zs ? 1 : 0,
                            cs, live, v, cache_len);
-        launch_mstats(st, (const float*)u, (const float*)logz, (const float*)cs, (const uint8_t*)live, (const float*)sup, (const float*)cnt, T, Q, K, y, 0);
+        // zero-shot: every class alive in the first outer iteration, a few per cent afterwards - the tile kernel over all classes,
+        // then over the lists of the live ones; few-shot: every class alive throughout
+        launch_mstats(st, (const float*)u, (const float*)logz, (const float*)cs, (const uint8_t*)live, (const float*)sup, (const float*)cnt, T, Q, K, y, 0,
+                      !zs || it == 0, (zs && it > 0) ? (int16_t*)(ws + L.cls) : nullptr, (zs && it > 0) ? (int32_t*)(ws + L.n_live) : nullptr);
         TCLIP_HIP(hipMemsetAsync(counts, 0, 256, st));
         TCLIP_HIP(hipMemsetAsync(dead_counts, 0, ((size_t)n_chunks + 3) * 4, st));
         TCLIP_HIP(hipMemsetAsync(stop, 0, (size_t)B * 4, st));
