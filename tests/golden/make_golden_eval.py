@@ -81,6 +81,9 @@ def main():
     if "K100more" in only:          # few-shot soft and zero-shot hard at the same class count and batch size
         only.discard("K100more")
         cases = [("fs", False, None, big), ("zs", True, None, big)]
+    if "K100r6" in only:            # (round 6) few-shot hard, and SOFT_KMEANS (configs[2]'s second method: the register-tiled statistics
+        only.discard("K100r6")      # kernel), at the same class count and batch size
+        cases = [("fs", True, None, big), ("zs", False, "SOFT_KMEANS", big)]
     for case in cases:
         kind, hard, other = case[:3]
         shape = case[3] if len(case) > 3 else {"K": 10, "number_tasks": 20, "batch_size": 10}

@@ -251,12 +251,13 @@ def test_bench_scale_call_equals_its_batches_run_alone():
 @pytest.mark.parametrize("name", ["eval_zs_soft_K10", "eval_zs_hard_K10", "eval_fs_soft_K10", "eval_fs_hard_K10", "eval_zs_soft_kmeans_K10",
                                   "eval_zs_hard_kmeans_K10", "eval_zs_em_gaussian_K10", "eval_zs_em_gaussian_cov_K10", "eval_zs_kl_kmeans_K10", "eval_zs_clip_K10",
                                   "eval_fs_paddle_K10", "eval_fs_bdcspn_K10", "eval_fs_alpha_tim_K10", "eval_fs_laplacian_shot_K10",
-                                  "eval_zs_soft_K100", "eval_zs_hard_K100", "eval_fs_soft_K100"])
+                                  "eval_zs_soft_K100", "eval_zs_hard_K100", "eval_fs_soft_K100", "eval_fs_hard_K100", "eval_zs_soft_kmeans_K100"])
 def test_task_batch_loop_matches_reference(name):
     """evaluate_tasks on the seeded synthetic table: the reference's mean accuracy (fixtures made
     by running the reference's Evaluator_*.evaluate_tasks), for every method behind the boundary.
-    eval_{zs_soft,zs_hard,fs_soft}_K100 (round 5) are the loops at a BASELINE class count - configs[1]'s shape, K = 100 with
-    batch_size = 100, two batches - and also hold every task's accuracy as the reference handed it to
+    eval_{zs_soft,zs_hard,fs_soft}_K100 (round 5) and eval_{fs_hard,zs_soft_kmeans}_K100 (round 6: the few-shot hard loop, and
+    SOFT_KMEANS through its register-tiled statistics kernel) are the loops at a BASELINE class count - configs[1]'s shape, K = 100
+    with batch_size = 100, two batches - and also hold every task's accuracy as the reference handed it to
     compute_confidence_interval (eval_zero_shot.py:176, eval_few_shot.py:258)."""
     from src.utils import CfgNode
     from tclip_amd import synth
