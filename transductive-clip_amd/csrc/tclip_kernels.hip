@@ -988,6 +988,9 @@ __global__ __launch_bounds__(256, (E > 16 ? TCLIP_MM_WAVES_LARGE : TCLIP_MM_WAVE
 // one wave evaluates digamma for all rows of the block in a single pass (one row per lane) inside the
 // dense-pass window instead of every 32-lane group evaluating its own row's value 32 times over.
 struct QueueCtl { int count[2][8]; int bad; float rowsum[2][64]; float psi[2][64]; };
+#ifdef TCLIP_COUNT_SMALL
+__device__ unsigned long long g_small_count[4];
+#endif
 
 // the row sum in torch's order, valid in lane 0 of the row's lane group (K >= 8; shorter rows: in every lane)
 template <int E, int G, int KC = 0>
@@ -1083,6 +1086,18 @@ __device__ __forceinline__ void mm_iterate_block(float (&beta)[R][E], const RowY
         ctl->psi[turn & 1][lane64] = digamma_pos_f32(ctl->rowsum[turn & 1][lane64], tab);
     __syncthreads();
     // phase C: per element digamma, cheap lgamma branch, pick-up, algebra
+#ifdef TCLIP_COUNT_SMALL
+    // design study (scripts/gpu_small_count.py): [0] wavefront-iterations of k_mm_live, [1] those that queued nothing, [2] block-iterations,
+    // [3] those in which NO wavefront of the block queued anything
+    if (lane64 == 0) {
+        atomicAdd(&g_small_count[0], 1ull);
+        if (base[R] == 0) atomicAdd(&g_small_count[1], 1ull);
+        if (wave == 0) {
+            atomicAdd(&g_small_count[2], 1ull);
+            if (n_big == 0) atomicAdd(&g_small_count[3], 1ull);
+        }
+    }
+#endif
     if (TCLIP_MM_SMALL_PATH && base[R] == 0) {                   // nothing of this wavefront's rows is in the queue (wave-uniform)
 #pragma unroll
         for (int r = 0; r < R; r++)
@@ -2172,6 +2187,9 @@ __global__ __launch_bounds__(256) void k_softmax(const float* logit0, const floa
 // 10^6 elements, oracle/mathcheck.cpp::mc_norm8).  One wavefront per task; lane j (and its seven copies 8 i + j) owns
 // accumulator j.  The chain of n/8 dependent FMAs per accumulator is inherent; everything else is kept off it (main loop
 // below).  (A variant with four tasks per wavefront and DPP operands had a quarter of the wavefronts and was slower.)
+#ifndef TCLIP_CRITERION_DEPTH
+#define TCLIP_CRITERION_DEPTH 32
+#endif
 __global__ __launch_bounds__(64) void k_criterion(const float* __restrict__ alpha, float* __restrict__ alpha_old, int K, int T,
                                                   float* __restrict__ ratio) {
     const int t = blockIdx.x, lane = threadIdx.x, j = lane & 7;
@@ -2193,7 +2211,11 @@ __global__ __launch_bounds__(64) void k_criterion(const float* __restrict__ alph
     // block's global loads are in flight.  (Round 2 fetched every operand with a cross-lane shuffle: 16 per 64 elements in front of 16 dependent FMAs,
     // ~400 cycles per 64 elements where the chains need ~100; one wavefront per task has nothing else to hide that behind,
     // which the few-shot runs - 33 tasks per stream - paid 20 times per run.)
-    constexpr int kDepth = 8, kRow = 64 + 4;                  // rows of 64 (d, o) pairs, 68 apart: the transposing 8-byte writes of a half-wavefront hit 32 different bank pairs
+    // kDepth x 64 elements per block (round 6: 32, i.e. 2048 elements; 8 until round 5): the next block's loads are issued before the
+    // current block's 8 kDepth dependent packed FMAs (~2000 clocks now), which is about a trip to HBM - with 512-element blocks a
+    // wavefront waited for memory three clocks out of four whenever the launch had too few tasks to cover it with other wavefronts
+    // (few-shot: 25-50 tasks per launch, 1.2 ms per call where the FMA chains need 0.45).  Same chains, same order.
+    constexpr int kDepth = TCLIP_CRITERION_DEPTH, kRow = 8 * kDepth + 4;    // rows of 8 kDepth (d, o) pairs, padded by 4: the transposing 8-byte writes of a half-wavefront hit 32 different bank pairs
     __shared__ __attribute__((aligned(16))) float2 sdo[8 * kRow];
     if (s0 + 64 * kDepth <= nv) {
         const int wi = lane >> 3;                             // this lane holds operand 8 k + wi of accumulator j in chunk k
@@ -2221,7 +2243,7 @@ __global__ __launch_bounds__(64) void k_criterion(const float* __restrict__ alph
             }
             __syncthreads();                                  // one wavefront per block: orders the LDS writes before the reads
 #pragma unroll
-            for (int m = 0; m < 32; m++) {
+            for (int m = 0; m < 4 * kDepth; m++) {
                 const float4 v = *reinterpret_cast<const float4*>(&sdo[j * kRow + 2 * m]);
                 const f2 p0{v.x, v.y}, p1{v.z, v.w};
                 acc = pk_fma(p0, p0, acc);
@@ -4499,6 +4521,15 @@ int tclip_profile_last_kernels(double* busy_ms, double* launch_ms_sum, int64_t* 
     return TCLIP_OK;
 }
 
+#ifdef TCLIP_COUNT_SMALL
+int tclip_debug_small_count(uint64_t* out) {        // reads and clears g_small_count (only in builds with -DTCLIP_COUNT_SMALL)
+    unsigned long long h[4];
+    TCLIP_HIP(hipMemcpyFromSymbol(h, HIP_SYMBOL(tclip::g_small_count), sizeof h));
+    for (int i = 0; i < 4; i++) { out[i] = h[i]; h[i] = 0; }
+    TCLIP_HIP(hipMemcpyToSymbol(HIP_SYMBOL(tclip::g_small_count), h, sizeof h));
+    return TCLIP_OK;
+}
+#endif
 #ifdef TCLIP_PHASE_CLOCK
 int tclip_debug_phase_clock(uint64_t* out) {        // reads and clears g_phase_clock (only in builds with -DTCLIP_PHASE_CLOCK)
     TCLIP_HIP(hipDeviceSynchronize());
