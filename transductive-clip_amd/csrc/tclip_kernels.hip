@@ -2187,8 +2187,11 @@ __global__ __launch_bounds__(256) void k_softmax(const float* logit0, const floa
 // 10^6 elements, oracle/mathcheck.cpp::mc_norm8).  One wavefront per task; lane j (and its seven copies 8 i + j) owns
 // accumulator j.  The chain of n/8 dependent FMAs per accumulator is inherent; everything else is kept off it (main loop
 // below).  (A variant with four tasks per wavefront and DPP operands had a quarter of the wavefronts and was slower.)
+#ifndef TCLIP_CRITERION_PACKED
+#define TCLIP_CRITERION_PACKED 1
+#endif
 #ifndef TCLIP_CRITERION_DEPTH
-#define TCLIP_CRITERION_DEPTH 32
+#define TCLIP_CRITERION_DEPTH 8
 #endif
 __global__ __launch_bounds__(64) void k_criterion(const float* __restrict__ alpha, float* __restrict__ alpha_old, int K, int T,
                                                   float* __restrict__ ratio) {
@@ -2211,10 +2214,10 @@ __global__ __launch_bounds__(64) void k_criterion(const float* __restrict__ alph
     // block's global loads are in flight.  (Round 2 fetched every operand with a cross-lane shuffle: 16 per 64 elements in front of 16 dependent FMAs,
     // ~400 cycles per 64 elements where the chains need ~100; one wavefront per task has nothing else to hide that behind,
     // which the few-shot runs - 33 tasks per stream - paid 20 times per run.)
-    // kDepth x 64 elements per block (round 6: 32, i.e. 2048 elements; 8 until round 5): the next block's loads are issued before the
-    // current block's 8 kDepth dependent packed FMAs (~2000 clocks now), which is about a trip to HBM - with 512-element blocks a
-    // wavefront waited for memory three clocks out of four whenever the launch had too few tasks to cover it with other wavefronts
-    // (few-shot: 25-50 tasks per launch, 1.2 ms per call where the FMA chains need 0.45).  Same chains, same order.
+    // kDepth x 64 elements per block.  Round 6 measured what bounds a lone wavefront here (few-shot: 25-50 tasks per launch, 1.2 ms per
+    // call): not the look-ahead - blocks of 1024 / 2048 elements (one block's chain then lasts as long as a trip to HBM) were 3 % / 11 %
+    // SLOWER - and not the packed form - the two chains as interleaved plain v_fma_f32 were 12 % slower: the cadence of the dependent
+    // chain itself (~22 clocks per element), which is the reference's order (profiles/r06_ab_criterion.txt).
     constexpr int kDepth = TCLIP_CRITERION_DEPTH, kRow = 8 * kDepth + 4;    // rows of 8 kDepth (d, o) pairs, padded by 4: the transposing 8-byte writes of a half-wavefront hit 32 different bank pairs
     __shared__ __attribute__((aligned(16))) float2 sdo[8 * kRow];
     if (s0 + 64 * kDepth <= nv) {
@@ -2245,9 +2248,17 @@ __global__ __launch_bounds__(64) void k_criterion(const float* __restrict__ alph
 #pragma unroll
             for (int m = 0; m < 4 * kDepth; m++) {
                 const float4 v = *reinterpret_cast<const float4*>(&sdo[j * kRow + 2 * m]);
+#if TCLIP_CRITERION_PACKED
                 const f2 p0{v.x, v.y}, p1{v.z, v.w};
                 acc = pk_fma(p0, p0, acc);
                 acc = pk_fma(p1, p1, acc);
+#else
+                // the two chains as plain FMAs, interleaved (measured slower, see above)
+                acc.x = __builtin_fmaf(v.x, v.x, acc.x);
+                acc.y = __builtin_fmaf(v.y, v.y, acc.y);
+                acc.x = __builtin_fmaf(v.z, v.z, acc.x);
+                acc.y = __builtin_fmaf(v.w, v.w, acc.y);
+#endif
             }
             __syncthreads();                                  // ... and the reads before the next block's writes
         }
