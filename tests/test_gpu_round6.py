@@ -81,3 +81,39 @@ def test_early_probe_takes_the_dead_rows_off_the_first_chunk():
     t_old, t_new = sum(old.values()), sum(new.values())
     print(f"dead-row kernels: {t_old:.0f} us (whole first chunk + probe) -> {t_new:.0f} us (12 iterations + early probe): {old} -> {new}")
     assert t_new < 0.8 * t_old
+
+
+def test_headline_batch_with_and_without_the_round6_shortcuts():
+    """bench.py's headline batch (125 tasks x K = 1000 from the bench's own table, iter 20 x iter_mm 1000 - 125 000 rows, the two-stage stop
+    test, ~119 000 deaths after the first outer iteration): the round's shortcuts - the early probe of freshly dead rows, the M-step
+    statistics over compacted lists of the live classes - switched off one by one give the same bits, MM counts and criterions."""
+    from src.eval_zero_shot import Evaluator_zero_shot
+    from src.utils import CfgNode
+    from tclip_amd import _capi, engine, synth
+    import random
+    K, N = 1000, 125
+    feats, labels = synth.make_feature_table(K, 50, seed=2020)
+    cfg = CfgNode(iter=20, iter_mm=1000, num_classes_test=K, n_class=K, n_query=75, k_eff=5, T=30, use_softmax_feature=True,
+                  graph_matching=True, shots=0, number_tasks=N, batch_size=N, name_method="EM_DIRICHLET", used_test_set="test")
+    ev = Evaluator_zero_shot(device=torch.device(DEV), log_file=None, args=cfg)
+    random.seed(2020); np.random.seed(2020); torch.manual_seed(2020)
+    idx = ev.sample_indices(labels.numpy())
+    x = engine.gather_rows(feats.to(DEV), idx.reshape(-1)).view(N, 75, K)
+    runs = {}
+    try:
+        runs["default"] = _run(x, 1, K, 20, 1000, False)
+        engine.debug_set_dead_head(0)
+        runs["whole first chunk + k_mm_probe"] = _run(x, 1, K, 20, 1000, False)
+        engine.debug_set_dead_head(-1)
+        _capi.check(_capi.lib().tclip_debug_set_kmeans_tile(0), "tclip_debug_set_kmeans_tile")
+        runs["statistics by k_mstats_rows"] = _run(x, 1, K, 20, 1000, False)
+    finally:
+        engine.debug_set_dead_head(-1)
+        _capi.check(_capi.lib().tclip_debug_set_kmeans_tile(-1), "tclip_debug_set_kmeans_tile")
+    ref = runs["default"]
+    assert ref.mm_iters[0, 0] < 1000 and int(ref.mm_iters[0, 1:].min()) == 1000, ref.mm_iters.tolist()
+    dead = int((ref.u.sum(1) <= 1e-15).sum())
+    assert dead > 100000, dead                                # the shortcut's rows are the bulk of the batch
+    for name, r in runs.items():
+        for f in ("alpha", "u", "v", "preds", "mm_iters", "criterions"):
+            assert torch.equal(getattr(r, f), getattr(ref, f)), (name, f)
