@@ -3372,7 +3372,7 @@ __global__ __launch_bounds__(256) void k_live_class_lists(const uint8_t* __restr
     if (threadIdx.x == 0) n_live[t] = base;
 }
 
-// The same statistics as a register-tiled product for tasks whose classes are (nearly) all alive - SOFT_KMEANS (round 6).
+// The same statistics as a register-tiled product (round 6).
 // k_mstats_cols75 hands u to the arithmetic as wave-uniform scalar loads, eight dwords per query and eight packed
 // instructions that use them: the counters of round 5 showed its wavefronts waiting 68 % of their cycles on those loads
 // (s_load returns out of order, so every wait is for ALL of them, and the LDS reads of the feature column share the
@@ -3383,8 +3383,10 @@ __global__ __launch_bounds__(256) void k_live_class_lists(const uint8_t* __restr
 // u[t, 0..74, 64 classes] and f[t, 0..74, 64 columns] (38 KB) once.
 // Same operations in the same order per output as k_mstats_cols75 / k_mstats_rows: products u f added in query order, a0
 // dumped into a1 after every 16 queries, a0 + a1 + 0 + 0.  Rows of the cascade region only (k < k_rows).
-// It does the work of a whole tile for any live class in it: the host uses it only where clusters do not die in numbers
-// (SOFT_KMEANS; EM_GAUSSIAN keeps one cluster per task alive and stays with the column kernel, which skips by eight).
+// It does the work of a whole tile for any live class in it: the host uses it over all classes where clusters do not die in
+// numbers (SOFT_KMEANS, the first outer iteration of EM-Dirichlet, few-shot) and over the compacted list of the live classes
+// (cls / n_live, k_live_class_lists) for the later outer iterations of zero-shot EM-Dirichlet; EM_GAUSSIAN keeps one cluster
+// per task alive and stays with the column kernel, which skips by eight.
 // Blocks of one task share an XCD (task_tile_of_block).
 constexpr int kTileQ = 75, kTileBlock = 64;
 #ifndef TCLIP_TILE_STAGE_BOTH
