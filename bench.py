@@ -610,8 +610,7 @@ def main():
         }
         try:                                             # which unit of the pool this was: the MM launches' durations differ by up to 5 % between boxes
             props = torch.cuda.get_device_properties(dev)
-            line["device"] = {"name": props.name, "compute_units": props.multi_processor_count,
-                              "clock_mhz": getattr(props, "clock_rate", 0) // 1000, "hbm_gib": round(props.total_memory / 2 ** 30)}
+            line["device"] = {"name": props.name, "compute_units": props.multi_processor_count, "hbm_gib": round(props.total_memory / 2 ** 30)}
         except Exception:
             pass
         if dist_on:
