@@ -1,7 +1,9 @@
-"""Randomised parity sweep on the GPU box: python3 scripts/gpu_fuzz.py [n_cases] [seed] [full|large]
+"""Randomised parity sweep on the GPU box: python3 scripts/gpu_fuzz.py [n_cases] [seed] [full|large|mid]
 ("large": long rows, K = 300 ... 1024, short schedules - the register-heavy instantiations)
 ("full": the reference's whole 20 x 1000 / 10 x 1000 schedule on small problems, which exercises the
 stop test at every checkpoint, dead rows, their cache and the limit-cycle shortcut)
+("mid": the whole schedule at K = 47 ... 128, one or two tasks per batch: dead rows by the hundred per task, whose limit cycles
+have other periods than at K <= 40 - minutes of CPU oracle per case)
 Random (K, Q, tasks, batches, hard, few-shot, schedule) against the C++ oracle, bit for bit, each
 case run twice (run-to-run determinism)."""
 import os, random, sys, time
@@ -18,6 +20,8 @@ n_cases = int(sys.argv[1]) if len(sys.argv) > 1 else 40
 rng = random.Random(int(sys.argv[2]) if len(sys.argv) > 2 else 1)
 full = len(sys.argv) > 3 and sys.argv[3] == "full"
 large = len(sys.argv) > 3 and sys.argv[3] == "large"
+mid = len(sys.argv) > 3 and sys.argv[3] == "mid"
+full = full or mid
 bad = 0
 t0 = time.time()
 for case in range(n_cases):
@@ -28,12 +32,16 @@ for case in range(n_cases):
     B = rng.randint(1, 4)
     if full:
         K = rng.choice([2, 3, 5, 7, 8, 9, 10, 12, 16, 20, 33, 40])
+    if mid:
+        K, B, Q, few = rng.choice([47, 64, 65, 100, 101, 128]), rng.randint(1, 2), rng.choice([20, 75]), False
     if large:
         K, B = rng.choice([300, 397, 450, 512, 600, 640, 777, 900, 1000, 1024]), rng.randint(1, 2)
-    budget = (4e8 if full else (8e8 if large else 1.5e8)) / (K * K)                # element-updates the CPU oracle can afford
+    budget = (4e8 if (full and not mid) else (8e8 if large else 1.5e8)) / (K * K)                # element-updates the CPU oracle can afford
     iter_mm = 1000 if full else rng.choice([30, 51, 60, 101, 120, 151, 230])
     iters = (10 if hard else 20) if full else rng.randint(2, 4)
     N = max(1, min(6, int(budget / (iter_mm * iters * B))))
+    if mid:
+        N = rng.randint(1, 2)
     lambd = max(1, int(K / 5)) * Q
     x_q, _ = synth.make_query_tasks(B * N, K, seed=1000 + case, n_query=Q, k_eff=(min(3, K) if few else None))
     x_s = y_s = None
